@@ -1,0 +1,20 @@
+// Internal interface of the encoder's variable-length attention (see attention.hip).
+#pragma once
+#include "common.h"
+
+namespace ance {
+
+struct AttnArgs {
+    const _Float16 *qk;    // [T, 2 H]: Q (pre-scaled by 1/sqrt(64)) | K, row stride ld_qk
+    const _Float16 *vt;    // [H, ld_vt]: V^T, row = head * 64 + dim, column = seq_vtcol[s] + key
+    _Float16 *ctx;         // [T, H], row stride ld_ctx
+    const int *seq_off;    // [n_seq + 1] first token of each sequence in the packed batch
+    const int *seq_vtcol;  // [n_seq] first (8-aligned) V^T column of each sequence
+    int ld_qk, ld_vt, ld_ctx;
+    int n_heads;
+};
+
+size_t attention_lds_bytes(int max_seq_len);
+int launch_attention(const AttnArgs &args, int n_seq, int max_seq_len, hipStream_t stream);
+
+}  // namespace ance

@@ -1,0 +1,42 @@
+// Shared device/host helpers for the ance_amd HIP library (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <float.h>
+
+#include "../../include/ance_amd.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned long long u64;
+
+namespace ance {
+
+void set_last_error(const char *msg);
+int check_launch(const char *what);
+
+// ---- order-preserving packing of (score, row) into one u64 key -------------------------------
+// larger key  <=>  ranks earlier in the canonical order (score desc, row asc).
+// key 0 is the "empty" sentinel: every non-NaN score maps to a high word >= 0x007FFFFF.
+__host__ __device__ inline uint32_t order_f32(float s) {
+    s = s + 0.0f;  // -0.0 -> +0.0 so the two zeros compare equal
+    uint32_t u = __builtin_bit_cast(uint32_t, s);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__host__ __device__ inline float unorder_f32(uint32_t o) {
+    uint32_t u = (o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o;
+    return __builtin_bit_cast(float, u);
+}
+__host__ __device__ inline u64 pack_key(float s, uint32_t row) {
+    return ((u64)order_f32(s) << 32) | (u64)(0xFFFFFFFFu - row);
+}
+__host__ __device__ inline float key_score(u64 k) { return unorder_f32((uint32_t)(k >> 32)); }
+__host__ __device__ inline uint32_t key_row(u64 k) { return 0xFFFFFFFFu - (uint32_t)(k & 0xFFFFFFFFull); }
+
+__device__ inline int lane_id() { return (int)(threadIdx.x & 63); }
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+}  // namespace ance

@@ -1,0 +1,619 @@
+// Dual-encoder forward for gfx950: RoBERTa-base / BERT-base stack + ANCE head, variable-length
+// packed (pad tokens are never materialised).  Replaces, on the reference's hot path,
+//   model.module.query_emb / body_emb  (drivers/run_ann_data_gen.py:171-180)
+//   = transformers RobertaModel/BertModel forward + embeddingHead + norm (model/models.py:149-157,
+//     165-199, 235-259).
+//
+// Per micro-batch (<= max_tokens real tokens), per layer:
+//   QK   = h16 Wqk^T + b          (gemm EPI_QK, Q pre-scaled by 1/8)        [T, 1536] f16
+//   V^T  = Wv h16^T + b           (gemm EPI_VT, key-contiguous)             [768, cols] f16
+//   ctx  = softmax(Q K^T) V       (attention.hip)                           [T, 768] f16
+//   pre  = ctx Wo^T + b + h32     (gemm EPI_RES32)                          [T, 768] f32
+//   h    = LayerNorm(pre)         -> h32 (residual stream, fp32) and h16 (next MFMA operand)
+//   f    = gelu(h16 W1^T + b)     (gemm EPI_GELU)                           [T, 3072] f16
+//   pre  = f W2^T + b + h32 ; h = LayerNorm(pre)
+// then  emb = LayerNorm(Wh h32[cls] + bh)  (fp32)  or raw h32[cls] for DPR's BERT.
+// Precision: fp16 MFMA operands, fp32 accumulation, fp32 residual stream / LayerNorm / softmax.
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+
+#include "attention.h"
+#include "common.h"
+#include "gemm_f16.h"
+
+namespace ance {
+namespace {
+
+constexpr int H = 768;          // hidden size this build is specialised for
+constexpr int HEAD_OUT = 768;   // embeddingHead output (model/models.py:145)
+constexpr int S_CAP_MAX = 8192; // sequences per micro-batch
+constexpr int FETCH_CHUNK = 262144;
+
+// ------------------------------------------------------------------------------------ kernels --
+
+__global__ void cvt_f32_f16_kernel(const float *src, _Float16 *dst, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) dst[i] = (_Float16)src[i];
+}
+
+__device__ __forceinline__ int record_len(const int32_t *ids_or_rec, int64_t ld, const int32_t *lens, int64_t rec,
+                                          int L) {
+    int full;
+    if (lens) full = lens[rec];
+    else full = (int)__builtin_bswap32((uint32_t)ids_or_rec[rec * ld]);  // 4-byte big-endian header
+    return full < 0 ? 0 : (full > L ? L : full);
+}
+
+// lengths of records [r0, r0 + n) -> out (for the host-side planner when it has no host copy)
+__global__ void fetch_lens_kernel(const int32_t *base, int64_t ld, const int32_t *lens, int64_t r0, int n, int L,
+                                  int32_t *out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = record_len(base, ld, lens, r0 + i, L);
+}
+
+struct PlanArgs {
+    const int32_t *base;  // records (header mode: row = [len_be, ids...]) or ids
+    int64_t ld;           // row stride in int32
+    const int32_t *lens;  // nullptr in header mode
+    int hdr;              // 1: ids start at column 1
+    int64_t g0;           // first global sequence (record * n_chunks + chunk) of this micro-batch
+    int S;                // sequences in this micro-batch
+    int L, n_chunks, Lc;
+    int pad_id, arch;
+    int T, Tpad;          // real tokens / padded to 128 (host computed, same arithmetic)
+    int *seq_off, *seq_vtcol, *seq_len;
+    int *tok_id, *tok_pos, *tok_vtcol;
+};
+
+// effective lengths + exclusive scans (token offsets; 8-aligned V^T columns).  One block.
+__global__ void __launch_bounds__(1024) plan_kernel(const PlanArgs P) {
+    __shared__ int s_tot[1024], s_tot8[1024];
+    const int tid = threadIdx.x;
+    const int per = (P.S + 1023) / 1024;
+    const int b0 = tid * per;
+    int sum = 0, sum8 = 0;
+    for (int j = 0; j < per; ++j) {
+        const int s = b0 + j;
+        if (s < P.S) {
+            const int64_t gs = P.g0 + s;
+            const int64_t rec = gs / P.n_chunks;
+            const int c = (int)(gs - rec * P.n_chunks);
+            const int full = record_len(P.base, P.ld, P.lens, rec, P.L);
+            int lc = full - c * P.Lc;
+            lc = lc < 0 ? 0 : (lc > P.Lc ? P.Lc : lc);
+            P.seq_len[s] = lc;
+            const int eff = lc > 0 ? lc : 1;
+            sum += eff;
+            sum8 += (eff + 7) & ~7;
+        }
+    }
+    s_tot[tid] = sum;
+    s_tot8[tid] = sum8;
+    __syncthreads();
+    // Hillis-Steele inclusive scan over 1024 partials
+    for (int off = 1; off < 1024; off <<= 1) {
+        int a = 0, a8 = 0;
+        if (tid >= off) {
+            a = s_tot[tid - off];
+            a8 = s_tot8[tid - off];
+        }
+        __syncthreads();
+        s_tot[tid] += a;
+        s_tot8[tid] += a8;
+        __syncthreads();
+    }
+    int run = s_tot[tid] - sum, run8 = s_tot8[tid] - sum8;
+    for (int j = 0; j < per; ++j) {
+        const int s = b0 + j;
+        if (s < P.S) {
+            const int lc = P.seq_len[s];
+            const int eff = lc > 0 ? lc : 1;
+            P.seq_off[s] = run;
+            P.seq_vtcol[s] = run8;
+            run += eff;
+            run8 += (eff + 7) & ~7;
+        }
+    }
+    if (tid == 1023) P.seq_off[P.S] = s_tot[1023];
+}
+
+// one wave per sequence: packed token ids, position ids, V^T columns
+__global__ void __launch_bounds__(256) pack_kernel(const PlanArgs P) {
+    const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int l = threadIdx.x & 63;
+    if (s < P.S) {
+        const int64_t gs = P.g0 + s;
+        const int64_t rec = gs / P.n_chunks;
+        const int c = (int)(gs - rec * P.n_chunks);
+        const int lc = P.seq_len[s];
+        const int t0 = P.seq_off[s], v0 = P.seq_vtcol[s];
+        if (lc == 0) {
+            // all-pad chunk == one pad token attending to itself
+            if (l == 0) {
+                P.tok_id[t0] = P.pad_id;
+                P.tok_pos[t0] = P.arch == ANCE_ARCH_ROBERTA ? P.pad_id : 0;
+                P.tok_vtcol[t0] = v0;
+            }
+        } else {
+            const int32_t *src = P.base + rec * P.ld + P.hdr + c * P.Lc;
+            int before = 0;  // non-pad tokens seen so far (RoBERTa position ids)
+            for (int j0 = 0; j0 < lc; j0 += 64) {
+                const int j = j0 + l;
+                const bool in = j < lc;
+                const int id = in ? src[j] : P.pad_id;
+                const bool nonpad = in && id != P.pad_id;
+                const u64 m = __ballot(nonpad);
+                if (in) {
+                    int pos;
+                    if (P.arch == ANCE_ARCH_ROBERTA)
+                        pos = nonpad ? before + __popcll(m & ((2ull << l) - 1ull)) + P.pad_id : P.pad_id;
+                    else
+                        pos = j;
+                    P.tok_id[t0 + j] = id;
+                    P.tok_pos[t0 + j] = pos;
+                    P.tok_vtcol[t0 + j] = v0 + j;
+                }
+                before += __popcll(m);
+            }
+        }
+    }
+    // rows T..Tpad exist only to fill the last GEMM tile
+    const int gt = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gt < P.Tpad - P.T) {
+        P.tok_id[P.T + gt] = P.pad_id;
+        P.tok_pos[P.T + gt] = P.arch == ANCE_ARCH_ROBERTA ? P.pad_id : 0;
+        P.tok_vtcol[P.T + gt] = 0;
+    }
+}
+
+// LayerNorm of one 768-wide row held as 12 floats per lane (3 x float4, lane-contiguous)
+__device__ __forceinline__ void ln_row_store(f32x4 v0, f32x4 v1, f32x4 v2, const float *gamma, const float *beta,
+                                             float eps, float *out32, _Float16 *out16, int l) {
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) s += v0[j] + v1[j] + v2[j];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    const float mean = s * (1.0f / H);
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float a = v0[j] - mean, b = v1[j] - mean, c = v2[j] - mean;
+        q += a * a + b * b + c * c;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) q += __shfl_xor(q, off);
+    const float rstd = rsqrtf(q * (1.0f / H) + eps);
+    const f32x4 *g4 = reinterpret_cast<const f32x4 *>(gamma);
+    const f32x4 *b4 = reinterpret_cast<const f32x4 *>(beta);
+    f32x4 vin[3] = {v0, v1, v2};
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        const int c4 = p * 64 + l;  // float4 index within the row
+        const f32x4 gg = g4[c4], bb = b4[c4];
+        f32x4 y;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) y[j] = (vin[p][j] - mean) * rstd * gg[j] + bb[j];
+        if (out32) reinterpret_cast<f32x4 *>(out32)[c4] = y;
+        if (out16) reinterpret_cast<f16x4 *>(out16)[c4] = f16x4{(_Float16)y[0], (_Float16)y[1], (_Float16)y[2], (_Float16)y[3]};
+    }
+}
+
+// embeddings (modeling_roberta.py:75-121): word[id] + type[0] + pos[p], LayerNorm
+__global__ void __launch_bounds__(256) embed_ln_kernel(const int *tok_id, const int *tok_pos, int Tpad, const float *word,
+                                                       const float *pos, const float *type0, int vocab, int max_pos,
+                                                       const float *gamma, const float *beta, float eps, float *h32,
+                                                       _Float16 *h16) {
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int l = threadIdx.x & 63;
+    if (t >= Tpad) return;
+    int id = tok_id[t], p = tok_pos[t];
+    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+    p = p < 0 ? 0 : (p >= max_pos ? max_pos - 1 : p);
+    const f32x4 *w4 = reinterpret_cast<const f32x4 *>(word + (size_t)id * H);
+    const f32x4 *p4 = reinterpret_cast<const f32x4 *>(pos + (size_t)p * H);
+    const f32x4 *t4 = reinterpret_cast<const f32x4 *>(type0);
+    f32x4 v[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int c4 = k * 64 + l;
+        v[k] = (w4[c4] + t4[c4]) + p4[c4];  // same association as the reference: (word + type) + pos
+    }
+    ln_row_store(v[0], v[1], v[2], gamma, beta, eps, h32 + (size_t)t * H, h16 + (size_t)t * H, l);
+}
+
+__global__ void __launch_bounds__(256) ln_kernel(const float *pre, int Tpad, const float *gamma, const float *beta, float eps,
+                                                 float *h32, _Float16 *h16) {
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int l = threadIdx.x & 63;
+    if (t >= Tpad) return;
+    const f32x4 *x4 = reinterpret_cast<const f32x4 *>(pre + (size_t)t * H);
+    ln_row_store(x4[l], x4[64 + l], x4[128 + l], gamma, beta, eps, h32 + (size_t)t * H, h16 + (size_t)t * H, l);
+}
+
+// head: emb = LayerNorm_768(W h_cls + b) (model/models.py:152-153), or raw h_cls (models.py:239)
+__global__ void __launch_bounds__(256) head_kernel(const float *h32, const int *seq_off, const float *W, const float *b,
+                                                   const float *gamma, const float *beta, int has_head, float *out) {
+    __shared__ float cls[H];
+    __shared__ float z[HEAD_OUT];
+    __shared__ float red[8];
+    const int s = blockIdx.x, tid = threadIdx.x;
+    const float *src = h32 + (size_t)seq_off[s] * H;
+    float *dst = out + (size_t)s * HEAD_OUT;
+    if (!has_head) {
+        for (int j = tid; j < H; j += 256) dst[j] = src[j];
+        return;
+    }
+    for (int j = tid; j < H; j += 256) cls[j] = src[j];
+    __syncthreads();
+    // each wave computes output features n = w, w+4, ...: lanes split k, reduce by shuffle
+    const int w = tid >> 6, l = tid & 63;
+    for (int n = w; n < HEAD_OUT; n += 4) {
+        const float *wr = W + (size_t)n * H;
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < H / 64; ++k) acc = fmaf(wr[k * 64 + l], cls[k * 64 + l], acc);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+        if (l == 0) z[n] = acc + b[n];
+    }
+    __syncthreads();
+    float sm = 0.f;
+    for (int j = tid; j < HEAD_OUT; j += 256) sm += z[j];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sm += __shfl_xor(sm, off);
+    if (l == 0) red[w] = sm;
+    __syncthreads();
+    const float mean = (red[0] + red[1] + red[2] + red[3]) * (1.0f / HEAD_OUT);
+    float q = 0.f;
+    for (int j = tid; j < HEAD_OUT; j += 256) {
+        const float a = z[j] - mean;
+        q += a * a;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) q += __shfl_xor(q, off);
+    if (l == 0) red[4 + w] = q;
+    __syncthreads();
+    const float rstd = rsqrtf((red[4] + red[5] + red[6] + red[7]) * (1.0f / HEAD_OUT) + 1e-5f);
+    for (int j = tid; j < HEAD_OUT; j += 256) dst[j] = (z[j] - mean) * rstd * gamma[j] + beta[j];
+}
+
+// ------------------------------------------------------------------------------- host layout --
+
+struct LayerW {
+    _Float16 *wqk, *wv, *wo, *w1, *w2;
+    float *bqk, *bv, *bo, *b1, *b2, *ln1w, *ln1b, *ln2w, *ln2b;
+};
+
+struct Arena {
+    size_t off = 0;
+    char *base = nullptr;
+    template <typename T>
+    T *take(size_t n) {
+        T *p = base ? reinterpret_cast<T *>(base + off) : nullptr;
+        off = align_up(off + n * sizeof(T), 256);
+        return p;
+    }
+};
+
+}  // namespace
+}  // namespace ance
+
+using namespace ance;
+
+struct AnceEncoder {
+    AnceEncoderDesc d;
+    // weights
+    float *word, *pos, *type0, *eln_w, *eln_b;
+    std::vector<LayerW> layers;
+    float *head_w, *head_b, *norm_w, *norm_b;
+    // workspace
+    int tcap, vcap, scap;
+    int *seq_off, *seq_vtcol, *seq_len, *tok_id, *tok_pos, *tok_vtcol, *lens_fetch;
+    float *h32, *pre32;
+    _Float16 *h16, *qk16, *vt16, *ctx16, *ffn16;
+    std::vector<int32_t> host_lens;
+};
+
+namespace {
+
+bool desc_ok(const AnceEncoderDesc *d) {
+    return d && d->hidden == H && d->n_heads == 12 && d->intermediate > 0 && d->intermediate % 128 == 0 &&
+           d->n_layers >= 1 && d->vocab_size > 0 && d->max_position > 0 && d->max_seq_len >= 1 &&
+           d->max_seq_len <= 512 && d->max_tokens >= 512 && d->max_tokens % 128 == 0 &&
+           (d->arch == ANCE_ARCH_ROBERTA || d->arch == ANCE_ARCH_BERT);
+}
+
+void layout_weights(const AnceEncoderDesc *d, Arena &a, AnceEncoder *e) {
+    const size_t I = d->intermediate;
+    float *word = a.take<float>((size_t)d->vocab_size * H);
+    float *pos = a.take<float>((size_t)d->max_position * H);
+    float *type0 = a.take<float>(H);
+    float *ew = a.take<float>(H), *eb = a.take<float>(H);
+    if (e) { e->word = word; e->pos = pos; e->type0 = type0; e->eln_w = ew; e->eln_b = eb; e->layers.resize(d->n_layers); }
+    for (int i = 0; i < d->n_layers; ++i) {
+        LayerW w;
+        w.wqk = a.take<_Float16>((size_t)2 * H * H);
+        w.bqk = a.take<float>(2 * H);
+        w.wv = a.take<_Float16>((size_t)H * H);
+        w.bv = a.take<float>(H);
+        w.wo = a.take<_Float16>((size_t)H * H);
+        w.bo = a.take<float>(H);
+        w.ln1w = a.take<float>(H);
+        w.ln1b = a.take<float>(H);
+        w.w1 = a.take<_Float16>(I * H);
+        w.b1 = a.take<float>(I);
+        w.w2 = a.take<_Float16>((size_t)H * I);
+        w.b2 = a.take<float>(H);
+        w.ln2w = a.take<float>(H);
+        w.ln2b = a.take<float>(H);
+        if (e) e->layers[i] = w;
+    }
+    float *hw = nullptr, *hb = nullptr, *nw = nullptr, *nb = nullptr;
+    if (d->has_head) {
+        hw = a.take<float>((size_t)HEAD_OUT * H);
+        hb = a.take<float>(HEAD_OUT);
+        nw = a.take<float>(HEAD_OUT);
+        nb = a.take<float>(HEAD_OUT);
+    }
+    if (e) { e->head_w = hw; e->head_b = hb; e->norm_w = nw; e->norm_b = nb; }
+}
+
+void layout_workspace(const AnceEncoderDesc *d, Arena &a, AnceEncoder *e) {
+    const int tcap = d->max_tokens;
+    const int scap = tcap < S_CAP_MAX ? tcap : S_CAP_MAX;
+    const int vcap = (int)align_up((size_t)tcap + tcap / 4 + 128, 128);
+    int *seq_off = a.take<int>(scap + 1), *seq_vtcol = a.take<int>(scap), *seq_len = a.take<int>(scap);
+    int *tok_id = a.take<int>(tcap), *tok_pos = a.take<int>(tcap), *tok_vtcol = a.take<int>(tcap);
+    int *lens_fetch = a.take<int>(FETCH_CHUNK);
+    float *h32 = a.take<float>((size_t)tcap * H), *pre32 = a.take<float>((size_t)tcap * H);
+    _Float16 *h16 = a.take<_Float16>((size_t)tcap * H);
+    _Float16 *qk16 = a.take<_Float16>((size_t)tcap * 2 * H);
+    _Float16 *vt16 = a.take<_Float16>((size_t)H * vcap);
+    _Float16 *ctx16 = a.take<_Float16>((size_t)tcap * H);
+    _Float16 *ffn16 = a.take<_Float16>((size_t)tcap * d->intermediate);
+    if (e) {
+        e->tcap = tcap; e->scap = scap; e->vcap = vcap;
+        e->seq_off = seq_off; e->seq_vtcol = seq_vtcol; e->seq_len = seq_len;
+        e->tok_id = tok_id; e->tok_pos = tok_pos; e->tok_vtcol = tok_vtcol; e->lens_fetch = lens_fetch;
+        e->h32 = h32; e->pre32 = pre32; e->h16 = h16; e->qk16 = qk16; e->vt16 = vt16; e->ctx16 = ctx16; e->ffn16 = ffn16;
+    }
+}
+
+void cvt16(const void *src, _Float16 *dst, size_t n, hipStream_t st) {
+    const unsigned blocks = (unsigned)((n + 256 * 8 - 1) / (256 * 8));
+    hipLaunchKernelGGL(cvt_f32_f16_kernel, dim3(blocks > 4096 ? 4096 : (blocks ? blocks : 1)), dim3(256), 0, st,
+                       (const float *)src, dst, n);
+}
+void cpy32(const void *src, float *dst, size_t n, hipStream_t st) {
+    (void)hipMemcpyAsync(dst, src, n * sizeof(float), hipMemcpyDeviceToDevice, st);
+}
+
+int encode_impl(AnceEncoder *e, const int32_t *base, int64_t ld, const int32_t *d_lens, const int32_t *h_lens, int hdr,
+                int64_t n, int L, int n_chunks, float *d_out, hipStream_t st) {
+    if (!e || !base || !d_out || n < 0 || L < 1 || n_chunks < 1 || L % n_chunks) {
+        set_last_error("ance_encode: invalid argument");
+        return ANCE_E_INVALID;
+    }
+    const int Lc = L / n_chunks;
+    if (Lc > e->d.max_seq_len) {
+        set_last_error("ance_encode: chunk length exceeds desc.max_seq_len");
+        return ANCE_E_INVALID;
+    }
+    const AnceEncoderDesc &D = e->d;
+    const int I = D.intermediate;
+
+    for (int64_t r0 = 0; r0 < n; r0 += FETCH_CHUNK) {
+        const int nr = (int)((n - r0) < FETCH_CHUNK ? (n - r0) : FETCH_CHUNK);
+        const int32_t *hl;
+        if (h_lens) {
+            hl = h_lens + r0;
+        } else {
+            // no host copy of the lengths: read them back once (the only synchronising path)
+            e->host_lens.resize(nr);
+            hipLaunchKernelGGL(fetch_lens_kernel, dim3((nr + 255) / 256), dim3(256), 0, st, base, ld, d_lens, r0, nr, L,
+                               e->lens_fetch);
+            if (hipMemcpyAsync(e->host_lens.data(), e->lens_fetch, (size_t)nr * 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
+                hipStreamSynchronize(st) != hipSuccess)
+                return check_launch("ance_encode: length read-back");
+            hl = e->host_lens.data();
+        }
+        // ---- greedy micro-batches over the sequences (record, chunk) of this block of records ---
+        const int64_t gs_end = (int64_t)nr * n_chunks;
+        int64_t gs = 0;
+        while (gs < gs_end) {
+            int S = 0, T = 0, V = 0, maxlen = 1;
+            int64_t g = gs;
+            while (g < gs_end && S < e->scap) {
+                const int64_t rec = g / n_chunks;
+                const int c = (int)(g - rec * n_chunks);
+                int full = hl[rec];
+                full = full < 0 ? 0 : (full > L ? L : full);
+                int lc = full - c * Lc;
+                lc = lc < 0 ? 0 : (lc > Lc ? Lc : lc);
+                const int eff = lc > 0 ? lc : 1;
+                const int v8 = (eff + 7) & ~7;
+                if (T + eff > e->tcap || V + v8 > e->vcap - 128) break;
+                T += eff; V += v8; ++S; ++g;
+                if (eff > maxlen) maxlen = eff;
+            }
+            if (S == 0) {
+                set_last_error("ance_encode: max_tokens too small for one sequence");
+                return ANCE_E_INVALID;
+            }
+            const int Tpad = (int)align_up((size_t)T, 128);
+            const int ldvt = (int)align_up((size_t)V, 128);
+
+            PlanArgs P;
+            P.base = base; P.ld = ld; P.lens = d_lens; P.hdr = hdr;
+            P.g0 = r0 * n_chunks + gs; P.S = S; P.L = L; P.n_chunks = n_chunks; P.Lc = Lc;
+            P.pad_id = D.pad_token_id; P.arch = D.arch; P.T = T; P.Tpad = Tpad;
+            P.seq_off = e->seq_off; P.seq_vtcol = e->seq_vtcol; P.seq_len = e->seq_len;
+            P.tok_id = e->tok_id; P.tok_pos = e->tok_pos; P.tok_vtcol = e->tok_vtcol;
+            hipLaunchKernelGGL(plan_kernel, dim3(1), dim3(1024), 0, st, P);
+            {
+                const int nb_seq = (S + 3) / 4, nb_pad = (Tpad - T + 255) / 256;
+                hipLaunchKernelGGL(pack_kernel, dim3(nb_seq > nb_pad ? nb_seq : nb_pad), dim3(256), 0, st, P);
+            }
+            hipLaunchKernelGGL(embed_ln_kernel, dim3(Tpad / 4), dim3(256), 0, st, e->tok_id, e->tok_pos, Tpad, e->word, e->pos,
+                               e->type0, D.vocab_size, D.max_position, e->eln_w, e->eln_b, D.ln_eps, e->h32, e->h16);
+            for (int li = 0; li < D.n_layers; ++li) {
+                const LayerW &W = e->layers[li];
+                GemmArgs G;
+                memset(&G, 0, sizeof(G));
+                // Q | K projection
+                G.A = e->h16; G.lda = H; G.B = W.wqk; G.ldb = H; G.M = Tpad; G.N = 2 * H; G.K = H;
+                G.bias = W.bqk; G.out16 = e->qk16; G.ldc = 2 * H; G.scale = 0.125f; G.scale_cols = H;
+                int rc = launch_gemm_f16(EPI_QK, G, st);
+                if (rc) return rc;
+                // V^T = Wv h^T
+                memset(&G, 0, sizeof(G));
+                G.A = W.wv; G.lda = H; G.B = e->h16; G.ldb = H; G.M = H; G.N = Tpad; G.K = H;
+                G.bias = W.bv; G.out16 = e->vt16; G.ldc = ldvt; G.col_map = e->tok_vtcol; G.n_valid = T;
+                rc = launch_gemm_f16(EPI_VT, G, st);
+                if (rc) return rc;
+                AttnArgs A;
+                A.qk = e->qk16; A.vt = e->vt16; A.ctx = e->ctx16; A.seq_off = e->seq_off; A.seq_vtcol = e->seq_vtcol;
+                A.ld_qk = 2 * H; A.ld_vt = ldvt; A.ld_ctx = H; A.n_heads = D.n_heads;
+                rc = launch_attention(A, S, maxlen, st);
+                if (rc) return rc;
+                // attention.output.dense + residual
+                memset(&G, 0, sizeof(G));
+                G.A = e->ctx16; G.lda = H; G.B = W.wo; G.ldb = H; G.M = Tpad; G.N = H; G.K = H;
+                G.bias = W.bo; G.out32 = e->pre32; G.res32 = e->h32; G.ldc = H;
+                rc = launch_gemm_f16(EPI_RES32, G, st);
+                if (rc) return rc;
+                hipLaunchKernelGGL(ln_kernel, dim3(Tpad / 4), dim3(256), 0, st, e->pre32, Tpad, W.ln1w, W.ln1b, D.ln_eps, e->h32,
+                                   e->h16);
+                // intermediate.dense + GELU
+                memset(&G, 0, sizeof(G));
+                G.A = e->h16; G.lda = H; G.B = W.w1; G.ldb = H; G.M = Tpad; G.N = I; G.K = H;
+                G.bias = W.b1; G.out16 = e->ffn16; G.ldc = I;
+                rc = launch_gemm_f16(EPI_GELU, G, st);
+                if (rc) return rc;
+                // output.dense + residual
+                memset(&G, 0, sizeof(G));
+                G.A = e->ffn16; G.lda = I; G.B = W.w2; G.ldb = I; G.M = Tpad; G.N = H; G.K = I;
+                G.bias = W.b2; G.out32 = e->pre32; G.res32 = e->h32; G.ldc = H;
+                rc = launch_gemm_f16(EPI_RES32, G, st);
+                if (rc) return rc;
+                hipLaunchKernelGGL(ln_kernel, dim3(Tpad / 4), dim3(256), 0, st, e->pre32, Tpad, W.ln2w, W.ln2b, D.ln_eps, e->h32,
+                                   e->h16);
+            }
+            hipLaunchKernelGGL(head_kernel, dim3(S), dim3(256), 0, st, e->h32, e->seq_off, e->head_w, e->head_b, e->norm_w,
+                               e->norm_b, D.has_head, d_out + (size_t)(r0 * n_chunks + gs) * HEAD_OUT);
+            gs = g;
+        }
+    }
+    return check_launch("ance_encode");
+}
+
+}  // namespace
+
+extern "C" size_t ance_encoder_weight_bytes(const AnceEncoderDesc *desc) {
+    if (!desc_ok(desc)) return 0;
+    Arena a;
+    layout_weights(desc, a, nullptr);
+    return a.off + 256;
+}
+
+extern "C" size_t ance_encoder_workspace_bytes(const AnceEncoderDesc *desc) {
+    if (!desc_ok(desc)) return 0;
+    Arena a;
+    layout_workspace(desc, a, nullptr);
+    return a.off + 256;
+}
+
+extern "C" int ance_encoder_create(const AnceEncoderDesc *desc, const void *const *w, int n_weights, void *d_weight_arena,
+                                   size_t weight_bytes, void *d_workspace, size_t workspace_bytes, void *stream,
+                                   AnceEncoder **out) {
+    if (!desc_ok(desc) || !w || !out || !d_weight_arena || !d_workspace ||
+        n_weights != ANCE_ENCODER_N_WEIGHTS(desc->n_layers, desc->has_head)) {
+        set_last_error("ance_encoder_create: invalid descriptor or weight list");
+        return ANCE_E_INVALID;
+    }
+    for (int i = 0; i < n_weights; ++i)
+        if (!w[i]) {
+            set_last_error("ance_encoder_create: null weight pointer");
+            return ANCE_E_INVALID;
+        }
+    if (weight_bytes < ance_encoder_weight_bytes(desc) || workspace_bytes < ance_encoder_workspace_bytes(desc)) {
+        set_last_error("ance_encoder_create: arena or workspace too small");
+        return ANCE_E_WORKSPACE;
+    }
+    AnceEncoder *e = new (std::nothrow) AnceEncoder();
+    if (!e) return ANCE_E_NOMEM;
+    e->d = *desc;
+    Arena wa, xa;
+    wa.base = reinterpret_cast<char *>(align_up((uintptr_t)d_weight_arena, 256));
+    xa.base = reinterpret_cast<char *>(align_up((uintptr_t)d_workspace, 256));
+    layout_weights(desc, wa, e);
+    layout_workspace(desc, xa, e);
+    hipStream_t st = (hipStream_t)stream;
+    (void)hipMemsetAsync(xa.base, 0, xa.off, st);  // pad rows must never hold NaN bit patterns
+
+    const size_t I = desc->intermediate;
+    cpy32(w[0], e->word, (size_t)desc->vocab_size * H, st);
+    cpy32(w[1], e->pos, (size_t)desc->max_position * H, st);
+    cpy32(w[2], e->type0, H, st);
+    cpy32(w[3], e->eln_w, H, st);
+    cpy32(w[4], e->eln_b, H, st);
+    for (int i = 0; i < desc->n_layers; ++i) {
+        const void *const *p = w + 5 + 16 * i;
+        LayerW &L = e->layers[i];
+        cvt16(p[0], L.wqk, (size_t)H * H, st);                 // query
+        cvt16(p[2], L.wqk + (size_t)H * H, (size_t)H * H, st);  // key
+        cpy32(p[1], L.bqk, H, st);
+        cpy32(p[3], L.bqk + H, H, st);
+        cvt16(p[4], L.wv, (size_t)H * H, st);
+        cpy32(p[5], L.bv, H, st);
+        cvt16(p[6], L.wo, (size_t)H * H, st);
+        cpy32(p[7], L.bo, H, st);
+        cpy32(p[8], L.ln1w, H, st);
+        cpy32(p[9], L.ln1b, H, st);
+        cvt16(p[10], L.w1, I * H, st);
+        cpy32(p[11], L.b1, I, st);
+        cvt16(p[12], L.w2, (size_t)H * I, st);
+        cpy32(p[13], L.b2, H, st);
+        cpy32(p[14], L.ln2w, H, st);
+        cpy32(p[15], L.ln2b, H, st);
+    }
+    if (desc->has_head) {
+        const void *const *p = w + 5 + 16 * desc->n_layers;
+        cpy32(p[0], e->head_w, (size_t)HEAD_OUT * H, st);
+        cpy32(p[1], e->head_b, HEAD_OUT, st);
+        cpy32(p[2], e->norm_w, HEAD_OUT, st);
+        cpy32(p[3], e->norm_b, HEAD_OUT, st);
+    }
+    int rc = check_launch("ance_encoder_create");
+    if (rc) {
+        delete e;
+        return rc;
+    }
+    *out = e;
+    return ANCE_OK;
+}
+
+extern "C" void ance_encoder_destroy(AnceEncoder *enc) { delete enc; }
+
+extern "C" int ance_encode_records(AnceEncoder *enc, const void *d_records, const int32_t *h_lens, int64_t n, int L,
+                                   int n_chunks, float *d_out, void *stream) {
+    return encode_impl(enc, (const int32_t *)d_records, (int64_t)L + 1, nullptr, h_lens, 1, n, L, n_chunks, d_out,
+                       (hipStream_t)stream);
+}
+
+extern "C" int ance_encode_ids(AnceEncoder *enc, const int32_t *d_ids, int64_t ld_ids, const int32_t *d_lens,
+                               const int32_t *h_lens, int64_t n, int L, int n_chunks, float *d_out, void *stream) {
+    if (!d_lens) {
+        set_last_error("ance_encode_ids: d_lens is required");
+        return ANCE_E_INVALID;
+    }
+    return encode_impl(enc, d_ids, ld_ids, d_lens, h_lens, 0, n, L, n_chunks, d_out, (hipStream_t)stream);
+}
+
+extern "C" double ance_encoder_flops_per_sequence(int T) {
+    const double t = T;
+    return 169869312.0 * t + 36864.0 * t * t + 1179648.0;
+}

@@ -1,0 +1,156 @@
+/*
+ * ance_amd -- C ABI of the MI355X-native ANN hard-negative refresh path.
+ *
+ * The reference (microsoft/ANCE) has no FFI: its hot path calls two Python packages.  These
+ * entry points are what a binding for that path replaces, one for one:
+ *
+ *   ance_encode_*      <- model.module.query_emb / body_emb
+ *                         (drivers/run_ann_data_gen.py:171-180; model/models.py:149-157,165-199,
+ *                          235-259) i.e. transformers' RobertaModel / BertModel forward + head
+ *   ance_ip_topk       <- faiss.IndexFlatIP(dim).add(x); .search(q, k)
+ *                         (drivers/run_ann_data_gen.py:269-276,303; run_ann_data_gen_dpr.py:238-252)
+ *   ance_topk_merge    <- the shard-search-then-merge of utils/eval_mrr.py:173-183
+ *                         (all_gather of (D, I), concat, argsort) under the canonical order
+ *
+ * Conventions: plain pointers and sizes, no exceptions, no torch types.  Every pointer named
+ * d_* is DEVICE memory owned by the caller; nothing is allocated or freed behind the caller's
+ * back except the small host-side handle of ance_encoder_create.  All work is enqueued on the
+ * caller's hipStream_t (passed as void* so this header needs no HIP include) and is asynchronous;
+ * the functions never synchronise the device.  Return value: 0 on success, negative ANCE_E_* on
+ * error (nothing enqueued in that case).
+ *
+ * Canonical result order of every top-k list: score descending, then row id ascending.
+ * Scores are exact fp32: an fmaf chain over k = 0..d-1 ascending starting from +0.0f.
+ */
+#ifndef ANCE_AMD_H
+#define ANCE_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ANCE_OK 0
+#define ANCE_E_INVALID (-1)   /* bad argument (null pointer, k/d/L out of the supported range) */
+#define ANCE_E_WORKSPACE (-2) /* workspace too small */
+#define ANCE_E_LAUNCH (-3)    /* HIP reported a launch error */
+#define ANCE_E_NOMEM (-4)
+
+#define ANCE_ABI_VERSION 1
+int ance_abi_version(void);
+/* last HIP error string seen by this library on the calling thread ("" if none) */
+const char *ance_last_error(void);
+
+/* ------------------------------------------------------------------ exact IP top-k search -- */
+
+#define ANCE_TOPK_MAX_K 1792
+
+/* Bytes of scratch ance_ip_topk needs for (n rows, nq queries, k).  0 if unsupported. */
+size_t ance_ip_topk_workspace_bytes(int64_t n, int64_t nq, int k);
+
+/*
+ * Exact inner-product top-k of nq queries against one shard of n rows.
+ *   d_x   float32 [n, d] row-major, 16-byte aligned, d % 4 == 0
+ *   d_q   float32 [nq, d]
+ *   row_base  global id of the shard's first row (ids returned are row_base + local row)
+ *   d_out_d   float32 [nq, k] scores, canonical order; -FLT_MAX where fewer than k rows exist
+ *   d_out_i   int64   [nq, k] global row ids; -1 where fewer than k rows exist
+ * Requires n < 2^32, 1 <= k <= ANCE_TOPK_MAX_K.
+ */
+int ance_ip_topk(const float *d_x, int64_t n, int64_t row_base, const float *d_q, int64_t nq, int d, int k,
+                 float *d_out_d, int64_t *d_out_i, void *d_workspace, size_t workspace_bytes, void *stream);
+
+/* Bytes of scratch ance_topk_merge needs. */
+size_t ance_topk_merge_workspace_bytes(int n_parts, int64_t nq, int k);
+
+/*
+ * Merge n_parts canonical lists (e.g. one per corpus shard / GPU) into one.
+ *   d_parts_d float32 [n_parts, nq, k], d_parts_i int64 [n_parts, nq, k] (ids < 2^32, -1 = empty)
+ */
+int ance_topk_merge(const float *d_parts_d, const int64_t *d_parts_i, int n_parts, int64_t nq, int k,
+                    float *d_out_d, int64_t *d_out_i, void *d_workspace, size_t workspace_bytes, void *stream);
+
+/* ------------------------------------------------------------------------ dual encoder ------ */
+
+#define ANCE_ARCH_ROBERTA 0 /* positions = cumsum(id != pad) * (id != pad) + pad, type 0     */
+#define ANCE_ARCH_BERT 1    /* positions = 0..len-1, token type 0                              */
+
+typedef struct AnceEncoderDesc {
+    int32_t arch;         /* ANCE_ARCH_*                                                     */
+    int32_t n_layers;     /* 12                                                              */
+    int32_t hidden;       /* 768 (must be 768 in this build: 12 heads x 64)                  */
+    int32_t n_heads;      /* 12                                                              */
+    int32_t intermediate; /* 3072                                                            */
+    int32_t vocab_size;
+    int32_t max_position; /* rows of the position table (514 RoBERTa / 512 BERT)             */
+    int32_t pad_token_id; /* 1 RoBERTa / 0 BERT                                              */
+    float ln_eps;         /* 1e-5 RoBERTa / 1e-12 BERT (encoder LayerNorms)                  */
+    int32_t has_head;     /* 1: LayerNorm_768(W h_cls + b), eps 1e-5 (models.py:145-153); 0: raw h_cls */
+    int32_t max_seq_len;  /* longest single sequence (chunk) this handle will see, <= 512    */
+    int32_t max_tokens;   /* token capacity of one micro-batch (workspace sizing)            */
+} AnceEncoderDesc;
+
+typedef struct AnceEncoder AnceEncoder;
+
+/*
+ * Order of the fp32 device weight pointers handed to ance_encoder_create (HF state-dict names,
+ * prefix = "roberta." / "question_model." / "ctx_model."):
+ *   [0] embeddings.word_embeddings.weight        [vocab, H]
+ *   [1] embeddings.position_embeddings.weight    [max_position, H]
+ *   [2] embeddings.token_type_embeddings.weight  [>=1, H]   (row 0 used)
+ *   [3] embeddings.LayerNorm.weight  [4] embeddings.LayerNorm.bias
+ *   then per layer i (16 pointers, base 5 + 16 i):
+ *     +0 attention.self.query.weight  +1 .bias     +2 attention.self.key.weight   +3 .bias
+ *     +4 attention.self.value.weight  +5 .bias     +6 attention.output.dense.weight +7 .bias
+ *     +8 attention.output.LayerNorm.weight +9 .bias
+ *     +10 intermediate.dense.weight   +11 .bias    +12 output.dense.weight +13 .bias
+ *     +14 output.LayerNorm.weight     +15 .bias
+ *   then, if has_head: embeddingHead.weight, embeddingHead.bias, norm.weight, norm.bias
+ */
+#define ANCE_ENCODER_N_WEIGHTS(n_layers, has_head) (5 + 16 * (n_layers) + ((has_head) ? 4 : 0))
+
+/* Bytes of the packed weight arena (fp16 GEMM operands + fp32 vectors) and of the activation
+ * workspace for desc->max_tokens.  Both are caller-allocated device buffers, 256-byte aligned. */
+size_t ance_encoder_weight_bytes(const AnceEncoderDesc *desc);
+size_t ance_encoder_workspace_bytes(const AnceEncoderDesc *desc);
+
+/* Packs the fp32 weights into d_weight_arena (enqueued on stream; the fp32 sources may be freed
+ * once the stream has passed this point) and returns a handle bound to the two buffers. */
+int ance_encoder_create(const AnceEncoderDesc *desc, const void *const *d_weights_fp32, int n_weights,
+                        void *d_weight_arena, size_t weight_bytes, void *d_workspace, size_t workspace_bytes,
+                        void *stream, AnceEncoder **out);
+void ance_encoder_destroy(AnceEncoder *enc);
+
+/*
+ * Encode n records.  Each record is L int32 token ids split into n_chunks chunks of L / n_chunks
+ * tokens (n_chunks = 1: FirstP / queries; 4 with L = 2048: MaxP).  Pad tokens cost nothing: a
+ * chunk contributes only its first len_c = clamp(len - c * L/n_chunks, 0, L/n_chunks) tokens
+ * (an all-pad chunk is encoded as the single pad token it is equivalent to).
+ *   d_out float32 [n * n_chunks, 768], row = record * n_chunks + chunk.
+ *
+ * ance_encode_records: d_records = raw rows of the reference's tokenised cache
+ *   (utils/util.py:279-283): 4-byte BIG-endian length then L little-endian int32, record_bytes =
+ *   4 + 4 L, so the cache file can be copied to HBM verbatim.
+ * ance_encode_ids: d_ids int32 [n, L] (row stride ld_ids int32 elements), d_lens int32 [n].
+ *
+ * h_lens (HOST pointer, int32 [n], may be NULL): the same lengths the device will read, used by
+ *   the host-side micro-batch planner.  With h_lens the call never synchronises; with NULL the
+ *   library reads the lengths back once per 262,144 records (a stream synchronisation).
+ *   Precondition: h_lens[i] equals the record's header / d_lens[i].
+ */
+int ance_encode_records(AnceEncoder *enc, const void *d_records, const int32_t *h_lens, int64_t n, int L,
+                        int n_chunks, float *d_out, void *stream);
+int ance_encode_ids(AnceEncoder *enc, const int32_t *d_ids, int64_t ld_ids, const int32_t *d_lens,
+                    const int32_t *h_lens, int64_t n, int L, int n_chunks, float *d_out, void *stream);
+
+/* Introspection for tests / bench: algorithmic FLOPs of the last ance_encode_* call cannot be
+ * known without a sync, so the library exposes the pure function instead:
+ * F_enc(T) = 169,869,312 T + 36,864 T^2 + 1,179,648 per sequence of T tokens. */
+double ance_encoder_flops_per_sequence(int T);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ANCE_AMD_H */

@@ -1,0 +1,105 @@
+"""Synthetic MS MARCO-shaped data in the reference's on-disk formats (oracle / test infra).
+
+Formats follow the reference writers:
+
+* tokenised cache record = 4-byte big-endian ``passage_len`` + ``L`` x int32 (native LE)
+  (``data/msmarco_data.py:258,272`` minus the 8-byte id that the merge step strips,
+  ``data/msmarco_data.py:160-165``), ``<name>_meta`` JSON
+  ``{'type': 'int32', 'total_number': N, 'embedding_size': L}`` (``:171-176``).
+* ``train-qrel.tsv`` / ``dev-qrel.tsv``: ``qid_offset \t pid_offset \t rel`` (``:116-121``).
+
+Distributions are the ones SURVEY.md section 8(d) prescribes (config 1 / config 2).
+"""
+import json
+import os
+
+import numpy as np
+
+PAD, BOS, EOS = 1, 0, 2
+VOCAB = 50265
+
+
+def lognormal_lengths(rng, n, median, sigma, lo, hi):
+    x = rng.lognormal(mean=np.log(median), sigma=sigma, size=n)
+    return np.clip(np.rint(x), lo, hi).astype(np.int64)
+
+
+def make_records(rng, n, L, lengths, vocab=VOCAB, bos=BOS, eos=EOS, pad=PAD, lo_tok=3):
+    """int32 [n, 1+L] array: column 0 = length (host order, byte-swapped on write)."""
+    ids = rng.integers(lo_tok, vocab, size=(n, L), dtype=np.int64).astype(np.int32)
+    pos = np.arange(L)[None, :]
+    lens = lengths[:, None]
+    ids[:, 0] = bos
+    ids[np.arange(n), np.maximum(lengths - 1, 0)] = eos
+    ids[:, 0] = np.where(lengths > 0, bos, pad)
+    ids = np.where(pos < lens, ids, pad).astype(np.int32)
+    return ids
+
+
+def write_cache(path, ids, lengths):
+    """Write ``ids`` int32 [n, L] + ``lengths`` in the reference cache format."""
+    n, L = ids.shape
+    rec = np.empty((n, 4 + 4 * L), dtype=np.uint8)
+    rec[:, :4] = lengths.astype(">u4").view(np.uint8).reshape(n, 4)
+    rec[:, 4:] = np.ascontiguousarray(ids.astype("<i4")).view(np.uint8).reshape(n, 4 * L)
+    with open(path, "wb") as f:
+        f.write(rec.tobytes())
+    with open(path + "_meta", "w") as f:
+        json.dump({"type": "int32", "total_number": int(n), "embedding_size": int(L)}, f)
+
+
+def make_msmarco_like(out_dir, n_passages=10000, n_train=1000, n_dev=200, L=128, Lq=64,
+                      seed=1234, dup_frac=0.01, len_median=70, len_sigma=0.45,
+                      q_median=9, q_sigma=0.35):
+    """Config-1-style toy set.  Returns a dict of the arrays written."""
+    os.makedirs(out_dir, exist_ok=True)
+    rng = np.random.default_rng(seed)
+    plen = lognormal_lengths(rng, n_passages, len_median, len_sigma, 8, L)
+    pids = make_records(rng, n_passages, L, plen)
+    # planted exact duplicates (tie-break coverage)
+    n_dup = int(round(dup_frac * n_passages))
+    if n_dup > 0:
+        src = rng.integers(0, n_passages, size=n_dup)
+        dst = rng.integers(0, n_passages, size=n_dup)
+        pids[dst] = pids[src]
+        plen[dst] = plen[src]
+    write_cache(os.path.join(out_dir, "passages"), pids, plen)
+
+    def queries(n):
+        ql = lognormal_lengths(rng, n, q_median, q_sigma, 4, Lq)
+        return make_records(rng, n, Lq, ql), ql
+
+    tq, tql = queries(n_train)
+    dq, dql = queries(n_dev)
+    write_cache(os.path.join(out_dir, "train-query"), tq, tql)
+    write_cache(os.path.join(out_dir, "dev-query"), dq, dql)
+
+    train_pos = rng.integers(0, n_passages, size=n_train)
+    with open(os.path.join(out_dir, "train-qrel.tsv"), "w") as f:
+        for q, p in enumerate(train_pos):
+            f.write("%d\t%d\t1\n" % (q, p))
+    dev_rel = []
+    with open(os.path.join(out_dir, "dev-qrel.tsv"), "w") as f:
+        for q in range(n_dev):
+            m = int(rng.integers(1, 4))
+            ps = rng.choice(n_passages, size=m, replace=False)
+            for p in ps:
+                f.write("%d\t%d\t1\n" % (q, p))
+                dev_rel.append((q, int(p), 1))
+    return dict(passages=pids, passage_len=plen, train_query=tq, train_query_len=tql,
+                dev_query=dq, dev_query_len=dql, train_pos=train_pos, dev_rel=dev_rel)
+
+
+def ln_rows(rng, n, d=768, dtype=np.float32):
+    """Rows distributed like the reference head output at init: LayerNorm(N(0, I))
+    (SURVEY.md section 8(d), config 2 search-only restatement)."""
+    z = rng.standard_normal((n, d)).astype(np.float32)
+    z -= z.mean(axis=1, keepdims=True)
+    z /= np.sqrt((z * z).mean(axis=1, keepdims=True) + 1e-5)
+    return z.astype(dtype)
+
+
+def dyadic_rows(rng, n, d=768, levels=8, scale=1.0 / 16):
+    """Rows on a coarse dyadic grid: every product and partial sum is exact in fp32,
+    so inner products are order independent (test plan 3a)."""
+    return (rng.integers(-levels, levels + 1, size=(n, d)).astype(np.float32) * np.float32(scale))
