@@ -1,0 +1,386 @@
+"""The ANN hard-negative refresh job, MI355X-native (drop-in for drivers/run_ann_data_gen.py).
+
+Same CLI flags (seam B3, drivers/run_ann_data_gen.py:443-627), same inputs (B2: tokenised caches,
+qrels, ``checkpoint-N/`` dirs with the ``scheduler.pt`` commit marker) and the same outputs (B1:
+``ann_training_data_N`` then ``ann_ndcg_N``), so ``drivers/run_ann.py`` consumes them unchanged.
+
+What is different is where the work happens:
+  * every rank encodes a CONTIGUOUS block of records and keeps the fp32 embeddings in its own HBM
+    (the reference strides records over ranks and round-trips 27 GB through ``.npy`` files,
+    utils/util.py:87-146);
+  * search runs on every GPU against its resident shard (the reference searches on rank 0's CPU
+    with faiss, :265-303); per-shard top-k lists are all-gathered over RCCL and merged under the
+    canonical order (score desc, row id asc), so ``I`` is independent of the GPU count;
+  * row id == record offset (FirstP) or record * chunks + chunk (MaxP).
+
+Launch: one process per GPU, e.g.
+  python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 -m ance_amd.ann_data_gen ...
+"""
+import argparse
+import logging
+import os
+import random
+import time
+
+import numpy as np
+
+from . import negatives
+from .cache import TokenCache, shard_range
+
+logger = logging.getLogger(__name__)
+
+# ------------------------------------------------------------------------------------- helpers --
+
+
+def get_checkpoint_no(checkpoint_path):
+    """Last integer in the name (utils/util.py:224-226)."""
+    import re
+    nums = re.findall(r"\d+", checkpoint_path)
+    return int(nums[-1]) if nums else 0
+
+
+def get_latest_ann_data(ann_data_path):
+    """(n, path of ann_training_data_n, parsed ann_ndcg_n) of the newest refresh, or (-1, None, None)
+    (utils/util.py:229-243)."""
+    import json
+    prefix = "ann_ndcg_"
+    if not os.path.exists(ann_data_path):
+        return -1, None, None
+    nos = []
+    for s in next(os.walk(ann_data_path))[2]:
+        if s.startswith(prefix) and s[len(prefix):].isdigit():
+            nos.append(int(s[len(prefix):]))
+    if not nos:
+        return -1, None, None
+    no = max(nos)
+    with open(os.path.join(ann_data_path, prefix + str(no)), "r") as f:
+        ndcg_json = json.load(f)
+    return no, os.path.join(ann_data_path, "ann_training_data_" + str(no)), ndcg_json
+
+
+def get_latest_checkpoint(args):
+    """Newest ``training_dir/checkpoint-N`` that contains ``scheduler.pt`` -- the last file the
+    trainer writes, i.e. its commit marker -- else ``init_model_dir``
+    (drivers/run_ann_data_gen.py:55-71)."""
+    if not os.path.exists(args.training_dir):
+        return args.init_model_dir, 0
+    best = -1
+    for sub in next(os.walk(args.training_dir))[1]:
+        if os.path.exists(os.path.join(args.training_dir, sub, "scheduler.pt")):
+            best = max(best, get_checkpoint_no(sub))
+    if best >= 0:
+        return os.path.join(args.training_dir, "checkpoint-" + str(best)) + "/", best
+    return args.init_model_dir, 0
+
+
+class Dist:
+    """Thin view of torch.distributed that also works when no group is initialised."""
+
+    def __init__(self):
+        import torch.distributed as dist
+        self.dist = dist
+        self.on = dist.is_available() and dist.is_initialized()
+        self.rank = dist.get_rank() if self.on else 0
+        self.world = dist.get_world_size() if self.on else 1
+
+    def barrier(self):
+        if self.on:
+            self.dist.barrier()
+
+    def all_gather_rows(self, t, per):
+        """Concatenate per-rank row blocks (each padded to ``per`` rows) in rank order."""
+        import torch
+        if not self.on or self.world == 1:
+            return t
+        pad = torch.zeros((per,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        pad[:t.shape[0]] = t
+        parts = [torch.empty_like(pad) for _ in range(self.world)]
+        self.dist.all_gather(parts, pad)
+        return torch.cat(parts, dim=0)
+
+    def all_gather_stack(self, t):
+        """[world, *t.shape] of equal-shaped tensors."""
+        import torch
+        if not self.on or self.world == 1:
+            return t.unsqueeze(0)
+        t = t.contiguous()
+        parts = [torch.empty_like(t) for _ in range(self.world)]
+        self.dist.all_gather(parts, t)
+        return torch.stack(parts, dim=0)
+
+
+# -------------------------------------------------------------------------------------- engine --
+
+
+class HipEngine:
+    """Device operations of the job on one MI355X (C ABI of include/ance_amd.h).  The only engine the
+    product constructs; tests of the multi-process host logic inject a stand-in with this surface."""
+
+    def __init__(self, device=None, block_records=16384):
+        import torch
+        self.torch = torch
+        self.device = torch.device(device if device is not None else "cuda")
+        self.block_records = block_records
+
+    def encode_cache(self, model, cache, r0, r1, is_query, chunks=1):
+        """Embeddings of records [r0, r1) of a TokenCache -> device fp32 [(r1-r0) * chunks, 768]."""
+        torch = self.torch
+        enc = model.q if is_query else model.b
+        n = r1 - r0
+        out = torch.empty((n * chunks, 768), dtype=torch.float32, device=self.device)
+        if n == 0:
+            return out
+        rb = cache.record_size
+        B = min(self.block_records, n)
+        ring = [torch.empty((B, rb), dtype=torch.uint8).pin_memory() for _ in range(3)]
+        done = [None, None, None]
+        for bi, b0 in enumerate(range(0, n, B)):
+            b1 = min(b0 + B, n)
+            slot = bi % 3
+            if done[slot] is not None:
+                done[slot].synchronize()
+            host = ring[slot][:b1 - b0]
+            rec = cache.records(r0 + b0, r0 + b1)
+            host.numpy()[...] = rec
+            lens = cache.lengths(r0 + b0, r0 + b1)
+            dev = host.to(self.device, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            done[slot] = ev
+            enc.encode_records(dev, n_chunks=chunks, h_lens=lens, out=out[b0 * chunks:b1 * chunks])
+        return out
+
+    def search(self, x, row_base, q, k):
+        from .index import FlatIPIndex
+        idx = FlatIPIndex(x.shape[1], device=self.device, row_base=row_base)
+        idx.add(x)
+        return idx.search_device(q.contiguous(), k)
+
+    def merge(self, D_parts, I_parts):
+        from .index import topk_merge_device
+        return topk_merge_device(D_parts.contiguous(), I_parts.contiguous())
+
+    def to_numpy(self, t):
+        return t.detach().cpu().numpy()
+
+    def from_numpy(self, a):
+        return self.torch.from_numpy(np.ascontiguousarray(a)).to(self.device)
+
+
+def sharded_search(engine, dist, x_local, row_base, q_all, k):
+    """Exact top-k of ``q_all`` over the union of every rank's shard: local scan, all-gather of
+    the per-shard lists, canonical merge (the reference's own precedent: utils/eval_mrr.py:137-183)."""
+    D, I = engine.search(x_local, row_base, q_all, k)
+    if dist.world == 1:
+        return D, I
+    Dp = dist.all_gather_stack(D)
+    Ip = dist.all_gather_stack(I)
+    return engine.merge(Dp, Ip)
+
+
+def encode_collection(engine, dist, model, cache, is_query, chunks=1, r_begin=0, r_end=None):
+    """Each rank encodes a contiguous block; returns (local embeddings, first local row, n rows total)."""
+    n = len(cache) if r_end is None else r_end
+    s0, s1 = shard_range(n - r_begin, dist.rank, dist.world)
+    with cache as c:
+        emb = engine.encode_cache(model, c, r_begin + s0, r_begin + s1, is_query, chunks)
+    return emb, s0 * chunks, (n - r_begin) * chunks
+
+
+def gather_queries(dist, emb_local, n_total):
+    """All ranks end up with the full [n_total, 768] query matrix in record order."""
+    if dist.world == 1:
+        return emb_local
+    per = (n_total + dist.world - 1) // dist.world
+    out = dist.all_gather_rows(emb_local, per)
+    # blocks are contiguous and only the last ones can be short, so the real rows are a prefix of
+    # every block; compact them
+    if per * dist.world == n_total:
+        return out
+    keep = []
+    for r in range(dist.world):
+        s0, s1 = shard_range(n_total, r, dist.world)
+        keep.append(out[r * per:r * per + (s1 - s0)])
+    import torch
+    return torch.cat(keep, dim=0)
+
+
+# ----------------------------------------------------------------------------------- the job --
+
+
+def generate_new_ann(args, output_num, checkpoint_path, training_query_positive_id, dev_query_positive_id,
+                     latest_step_num, engine=None, model=None, dist=None):
+    """One refresh (drivers/run_ann_data_gen.py:231-336).  Returns (dev_ndcg, n_dev_queries) on rank 0."""
+    dist = dist or Dist()
+    if engine is None:
+        engine = HipEngine(getattr(args, "device", None))
+    if model is None:
+        from .encoder import load_model
+        model = load_model(args.model_type, checkpoint_path, max_seq_length=args.max_seq_length,
+                           max_tokens=getattr(args, "max_tokens", 32768), device=getattr(args, "device", None))
+    chunks = getattr(model, "chunks", 1)
+
+    logger.info("***** inference of dev query *****")
+    dev_cache = TokenCache(os.path.join(args.data_dir, "dev-query"))
+    dev_local, _, n_dev = encode_collection(engine, dist, model, dev_cache, True)
+
+    logger.info("***** inference of passages *****")
+    p_cache = TokenCache(os.path.join(args.data_dir, "passages"))
+    p_local, p_row0, n_rows = encode_collection(engine, dist, model, p_cache, False, chunks)
+    logger.info("***** Done passage inference *****")
+
+    if args.inference:
+        _dump_inference(args, engine, dist, latest_step_num, dev_local, p_local, p_row0, chunks, None, 0)
+        dist.barrier()
+        return None
+
+    logger.info("***** inference of train query *****")
+    q_cache = TokenCache(os.path.join(args.data_dir, "train-query"))
+    nq_all = len(q_cache)
+    q_start, q_end = negatives.query_chunk(nq_all, output_num, args.ann_chunk_factor)
+    # only the chunk that will be searched is encoded: rows are independent, the result is the same
+    q_local, _, n_q = encode_collection(engine, dist, model, q_cache, True, 1, q_start, q_end)
+    logger.info("Chunked %d query from %d", n_q, nq_all)
+
+    dev_all = gather_queries(dist, dev_local, n_dev)
+    q_all = gather_queries(dist, q_local, n_q)
+
+    _, dev_I = sharded_search(engine, dist, p_local, p_row0, dev_all, 100)
+    _, I = sharded_search(engine, dist, p_local, p_row0, q_all, args.topk_training)
+    logger.info("***** Done ANN Index *****")
+
+    result = None
+    if dist.rank == 0:
+        dev_I = engine.to_numpy(dev_I)
+        I = engine.to_numpy(I)
+        # row -> pid: identity for FirstP, row // chunks for MaxP (one vector per 512-token chunk)
+        p2id = np.arange(n_rows, dtype=np.int64) // chunks
+        dev_q2id = np.arange(n_dev, dtype=np.int64)
+        q2id = np.arange(q_start, q_end, dtype=np.int64)
+        dev_ndcg, n_dev_eval = negatives.eval_dev_query(dev_q2id, p2id, dev_query_positive_id, dev_I)
+        print("Rank:" + str(dist.rank) + " --- ANN NDCG@10:" + str(dev_ndcg))
+        effective_q_id = set(q2id.tolist())
+        neg = negatives.generate_negative_passage_ids(q2id, p2id, training_query_positive_id, I, effective_q_id,
+                                                      args.negative_sample, args.ann_measure_topk_mrr, rank=dist.rank)
+        logger.info("***** Construct ANN Triplet *****")
+        os.makedirs(args.output_dir, exist_ok=True)
+        negatives.write_ann_files(args.output_dir, output_num, I.shape[0], q2id, effective_q_id,
+                                  training_query_positive_id, neg, dev_ndcg, checkpoint_path)
+        result = (dev_ndcg, n_dev_eval)
+    dist.barrier()
+    return result
+
+
+def _dump_inference(args, engine, dist, step, dev_local, p_local, p_row0, chunks, q_local, q_row0):
+    """``--inference`` dumps (seam B6): per-rank ``{prefix}_data_obj_{rank}.npy`` with the prefixes of
+    drivers/run_ann_data_gen.py:215-224,245,252 (consumed by evaluation/Calculate Metrics.ipynb)."""
+    os.makedirs(args.output_dir, exist_ok=True)
+
+    def dump(prefix, emb, row0, per_id):
+        e = engine.to_numpy(emb)
+        ids = np.arange(row0, row0 + e.shape[0], dtype=np.int64) // per_id
+        np.save(os.path.join(args.output_dir, "{}_emb_p__data_obj_{}.npy".format(prefix, dist.rank)), e,
+                allow_pickle=False)
+        np.save(os.path.join(args.output_dir, "{}_embid_p__data_obj_{}.npy".format(prefix, dist.rank)), ids,
+                allow_pickle=False)
+
+    dev_n = len(TokenCache(os.path.join(args.data_dir, "dev-query")))
+    dump("dev_query_" + str(step) + "_", dev_local, shard_range(dev_n, dist.rank, dist.world)[0], 1)
+    dump("passage_" + str(step) + "_", p_local, p_row0, chunks)
+
+
+def ann_data_gen(args, engine=None, dist=None):
+    """Poll loop: one refresh per new checkpoint (drivers/run_ann_data_gen.py:663-702)."""
+    dist = dist or Dist()
+    last_checkpoint = args.last_checkpoint_dir
+    ann_no, _, _ = get_latest_ann_data(args.output_dir)
+    output_num = ann_no + 1
+    logger.info("starting output number %d", output_num)
+    if dist.rank == 0:
+        os.makedirs(args.output_dir, exist_ok=True)
+        os.makedirs(args.cache_dir, exist_ok=True)
+    training_positive_id, dev_positive_id = negatives.load_positive_ids(args.data_dir)
+
+    while args.end_output_num == -1 or output_num <= args.end_output_num:
+        next_checkpoint, latest_step_num = get_latest_checkpoint(args)
+        if args.only_keep_latest_embedding_file:
+            latest_step_num = 0
+        if next_checkpoint == last_checkpoint:
+            time.sleep(getattr(args, "poll_seconds", 60))
+        else:
+            logger.info("start generate ann data number %d", output_num)
+            logger.info("next checkpoint at " + next_checkpoint)
+            generate_new_ann(args, output_num, next_checkpoint, training_positive_id, dev_positive_id,
+                             latest_step_num, engine=engine, dist=dist)
+            if args.inference:
+                break
+            logger.info("finished generating ann data number %d", output_num)
+            output_num += 1
+            last_checkpoint = next_checkpoint
+        dist.barrier()
+
+
+def get_arguments(argv=None):
+    """Flags of drivers/run_ann_data_gen.py:443-627 (same names, defaults and meaning)."""
+    p = argparse.ArgumentParser()
+    p.add_argument("--data_dir", required=True, type=str)
+    p.add_argument("--training_dir", required=True, type=str)
+    p.add_argument("--init_model_dir", required=True, type=str)
+    p.add_argument("--last_checkpoint_dir", default="", type=str)
+    p.add_argument("--model_type", required=True, type=str)
+    p.add_argument("--output_dir", required=True, type=str)
+    p.add_argument("--cache_dir", required=True, type=str)
+    p.add_argument("--end_output_num", default=-1, type=int)
+    p.add_argument("--max_seq_length", default=128, type=int)
+    p.add_argument("--max_query_length", default=64, type=int)
+    p.add_argument("--max_doc_character", default=10000, type=int)
+    p.add_argument("--per_gpu_eval_batch_size", default=128, type=int)
+    p.add_argument("--ann_chunk_factor", default=5, type=int)
+    p.add_argument("--topk_training", default=500, type=int)
+    p.add_argument("--negative_sample", default=5, type=int)
+    p.add_argument("--ann_measure_topk_mrr", default=False, action="store_true")
+    p.add_argument("--only_keep_latest_embedding_file", default=False, action="store_true")
+    p.add_argument("--no_cuda", action="store_true")
+    p.add_argument("--local_rank", "--local-rank", type=int, default=-1)
+    p.add_argument("--server_ip", type=str, default="")
+    p.add_argument("--server_port", type=str, default="")
+    p.add_argument("--inference", default=False, action="store_true")
+    p.add_argument("--config_name", default="", type=str)
+    p.add_argument("--tokenizer_name", default="", type=str)
+    # additions (not in the reference)
+    p.add_argument("--max_tokens", default=32768, type=int, help="tokens per encoder micro-batch")
+    p.add_argument("--seed", default=None, type=int, help="seed `random` before negative sampling")
+    return p.parse_args(argv)
+
+
+def set_env(args):
+    """One process per GPU over RCCL (backend name "nccl" on ROCm) -- drivers/run_ann_data_gen.py:630-660."""
+    import torch
+    if args.no_cuda:
+        raise RuntimeError("this job has no CPU path: the HIP kernels are the product (--no_cuda is not supported)")
+    if args.local_rank == -1 and "LOCAL_RANK" in os.environ:
+        args.local_rank = int(os.environ["LOCAL_RANK"])
+    if args.local_rank != -1:
+        torch.cuda.set_device(args.local_rank)
+        args.device = torch.device("cuda", args.local_rank)
+        torch.distributed.init_process_group(backend="nccl")
+        args.world_size = torch.distributed.get_world_size()
+        args.rank = torch.distributed.get_rank()
+    else:
+        args.device = torch.device("cuda")
+        args.world_size, args.rank = 1, 0
+    args.n_gpu = 1
+    logging.basicConfig(format="%(asctime)s - %(levelname)s - %(name)s -   %(message)s", datefmt="%m/%d/%Y %H:%M:%S",
+                        level=logging.INFO if args.local_rank in [-1, 0] else logging.WARN)
+
+
+def main(argv=None):
+    args = get_arguments(argv)
+    set_env(args)
+    if args.seed is not None:
+        random.seed(args.seed)
+    ann_data_gen(args)
+
+
+if __name__ == "__main__":
+    main()

@@ -17,6 +17,25 @@ namespace ance {
 void set_last_error(const char *msg);
 int check_launch(const char *what);
 
+// ---- optional per-kernel timing with HIP events on the launch stream (bench.py's roofline) ----
+enum ProfCat {
+    PC_PLAN = 0, PC_EMBED, PC_GEMM_QK, PC_GEMM_VT, PC_ATTN, PC_GEMM_OUT, PC_LN, PC_GEMM_FFN1, PC_GEMM_FFN2, PC_HEAD,
+    PC_SCAN, PC_FINALIZE, PC_COUNT
+};
+bool prof_enabled();
+void prof_begin(int cat, hipStream_t st, double work);
+void prof_end(hipStream_t st);
+struct ProfScope {  // brackets the launches made while it is alive (one category)
+    hipStream_t st;
+    bool on;
+    ProfScope(int cat, hipStream_t s, double work = 0.0) : st(s), on(prof_enabled()) {
+        if (on) prof_begin(cat, st, work);
+    }
+    ~ProfScope() {
+        if (on) prof_end(st);
+    }
+};
+
 // ---- order-preserving packing of (score, row) into one u64 key -------------------------------
 // larger key  <=>  ranks earlier in the canonical order (score desc, row asc).
 // key 0 is the "empty" sentinel: every non-NaN score maps to a high word >= 0x007FFFFF.

@@ -452,13 +452,17 @@ int encode_impl(AnceEncoder *e, const int32_t *base, int64_t ld, const int32_t *
             P.pad_id = D.pad_token_id; P.arch = D.arch; P.T = T; P.Tpad = Tpad;
             P.seq_off = e->seq_off; P.seq_vtcol = e->seq_vtcol; P.seq_len = e->seq_len;
             P.tok_id = e->tok_id; P.tok_pos = e->tok_pos; P.tok_vtcol = e->tok_vtcol;
-            hipLaunchKernelGGL(plan_kernel, dim3(1), dim3(1024), 0, st, P);
             {
+                ProfScope ps(PC_PLAN, st);
+                hipLaunchKernelGGL(plan_kernel, dim3(1), dim3(1024), 0, st, P);
                 const int nb_seq = (S + 3) / 4, nb_pad = (Tpad - T + 255) / 256;
                 hipLaunchKernelGGL(pack_kernel, dim3(nb_seq > nb_pad ? nb_seq : nb_pad), dim3(256), 0, st, P);
             }
+            {
+            ProfScope pe(PC_EMBED, st);
             hipLaunchKernelGGL(embed_ln_kernel, dim3(Tpad / 4), dim3(256), 0, st, e->tok_id, e->tok_pos, Tpad, e->word, e->pos,
                                e->type0, D.vocab_size, D.max_position, e->eln_w, e->eln_b, D.ln_eps, e->h32, e->h16);
+            }
             for (int li = 0; li < D.n_layers; ++li) {
                 const LayerW &W = e->layers[li];
                 GemmArgs G;
@@ -466,44 +470,72 @@ int encode_impl(AnceEncoder *e, const int32_t *base, int64_t ld, const int32_t *
                 // Q | K projection
                 G.A = e->h16; G.lda = H; G.B = W.wqk; G.ldb = H; G.M = Tpad; G.N = 2 * H; G.K = H;
                 G.bias = W.bqk; G.out16 = e->qk16; G.ldc = 2 * H; G.scale = 0.125f; G.scale_cols = H;
-                int rc = launch_gemm_f16(EPI_QK, G, st);
+                int rc;
+                {
+                    ProfScope ps(PC_GEMM_QK, st, 2.0 * T * (2.0 * H) * H);
+                    rc = launch_gemm_f16(EPI_QK, G, st);
+                }
                 if (rc) return rc;
                 // V^T = Wv h^T
                 memset(&G, 0, sizeof(G));
                 G.A = W.wv; G.lda = H; G.B = e->h16; G.ldb = H; G.M = H; G.N = Tpad; G.K = H;
                 G.bias = W.bv; G.out16 = e->vt16; G.ldc = ldvt; G.col_map = e->tok_vtcol; G.n_valid = T;
-                rc = launch_gemm_f16(EPI_VT, G, st);
+                {
+                    ProfScope ps(PC_GEMM_VT, st, 2.0 * T * (double)H * H);
+                    rc = launch_gemm_f16(EPI_VT, G, st);
+                }
                 if (rc) return rc;
                 AttnArgs A;
                 A.qk = e->qk16; A.vt = e->vt16; A.ctx = e->ctx16; A.seq_off = e->seq_off; A.seq_vtcol = e->seq_vtcol;
                 A.ld_qk = 2 * H; A.ld_vt = ldvt; A.ld_ctx = H; A.n_heads = D.n_heads;
-                rc = launch_attention(A, S, maxlen, st);
+                {
+                    ProfScope ps(PC_ATTN, st, 0.0);
+                    rc = launch_attention(A, S, maxlen, st);
+                }
                 if (rc) return rc;
                 // attention.output.dense + residual
                 memset(&G, 0, sizeof(G));
                 G.A = e->ctx16; G.lda = H; G.B = W.wo; G.ldb = H; G.M = Tpad; G.N = H; G.K = H;
                 G.bias = W.bo; G.out32 = e->pre32; G.res32 = e->h32; G.ldc = H;
-                rc = launch_gemm_f16(EPI_RES32, G, st);
+                {
+                    ProfScope ps(PC_GEMM_OUT, st, 2.0 * T * (double)H * H);
+                    rc = launch_gemm_f16(EPI_RES32, G, st);
+                }
                 if (rc) return rc;
-                hipLaunchKernelGGL(ln_kernel, dim3(Tpad / 4), dim3(256), 0, st, e->pre32, Tpad, W.ln1w, W.ln1b, D.ln_eps, e->h32,
-                                   e->h16);
+                {
+                    ProfScope ps(PC_LN, st);
+                    hipLaunchKernelGGL(ln_kernel, dim3(Tpad / 4), dim3(256), 0, st, e->pre32, Tpad, W.ln1w, W.ln1b, D.ln_eps,
+                                       e->h32, e->h16);
+                }
                 // intermediate.dense + GELU
                 memset(&G, 0, sizeof(G));
                 G.A = e->h16; G.lda = H; G.B = W.w1; G.ldb = H; G.M = Tpad; G.N = I; G.K = H;
                 G.bias = W.b1; G.out16 = e->ffn16; G.ldc = I;
-                rc = launch_gemm_f16(EPI_GELU, G, st);
+                {
+                    ProfScope ps(PC_GEMM_FFN1, st, 2.0 * T * (double)I * H);
+                    rc = launch_gemm_f16(EPI_GELU, G, st);
+                }
                 if (rc) return rc;
                 // output.dense + residual
                 memset(&G, 0, sizeof(G));
                 G.A = e->ffn16; G.lda = I; G.B = W.w2; G.ldb = I; G.M = Tpad; G.N = H; G.K = I;
                 G.bias = W.b2; G.out32 = e->pre32; G.res32 = e->h32; G.ldc = H;
-                rc = launch_gemm_f16(EPI_RES32, G, st);
+                {
+                    ProfScope ps(PC_GEMM_FFN2, st, 2.0 * T * (double)I * H);
+                    rc = launch_gemm_f16(EPI_RES32, G, st);
+                }
                 if (rc) return rc;
-                hipLaunchKernelGGL(ln_kernel, dim3(Tpad / 4), dim3(256), 0, st, e->pre32, Tpad, W.ln2w, W.ln2b, D.ln_eps, e->h32,
-                                   e->h16);
+                {
+                    ProfScope ps(PC_LN, st);
+                    hipLaunchKernelGGL(ln_kernel, dim3(Tpad / 4), dim3(256), 0, st, e->pre32, Tpad, W.ln2w, W.ln2b, D.ln_eps,
+                                       e->h32, e->h16);
+                }
             }
-            hipLaunchKernelGGL(head_kernel, dim3(S), dim3(256), 0, st, e->h32, e->seq_off, e->head_w, e->head_b, e->norm_w,
-                               e->norm_b, D.has_head, d_out + (size_t)(r0 * n_chunks + gs) * HEAD_OUT);
+            {
+                ProfScope ps(PC_HEAD, st);
+                hipLaunchKernelGGL(head_kernel, dim3(S), dim3(256), 0, st, e->h32, e->seq_off, e->head_w, e->head_b, e->norm_w,
+                                   e->norm_b, D.has_head, d_out + (size_t)(r0 * n_chunks + gs) * HEAD_OUT);
+            }
             gs = g;
         }
     }

@@ -403,7 +403,11 @@ extern "C" int ance_ip_topk(const float *d_x, int64_t n, int64_t row_base, const
         const int groups = (P.n_qt + gq - 1) / gq;
         const int groups_pad = (groups + 7) / 8 * 8;
         const unsigned blocks = (unsigned)groups_pad * 64u;
-        hipLaunchKernelGGL(scan, dim3(blocks), dim3(SCAN_THREADS), SCAN_LDS_BYTES, st, P);
+        {
+            ProfScope ps(PC_SCAN, st, 2.0 * (double)nqc * (double)n * (double)d);
+            hipLaunchKernelGGL(scan, dim3(blocks), dim3(SCAN_THREADS), SCAN_LDS_BYTES, st, P);
+        }
+        ProfScope pf(PC_FINALIZE, st);
         hipLaunchKernelGGL(topk_finalize_kernel<false>, dim3((unsigned)nqc), dim3(256), P2 * sizeof(u64), st, part,
                            (const float *)nullptr, (const int64_t *)nullptr, 1, nqc, m, P2, k, row_base,
                            d_out_d + (size_t)q0 * k, d_out_i + (size_t)q0 * k);
@@ -433,6 +437,7 @@ extern "C" int ance_topk_merge(const float *d_parts_d, const int64_t *d_parts_i,
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(topk_finalize_kernel<true>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)(P2 * sizeof(u64))) != hipSuccess)
         return check_launch("topk_merge attr");
+    ProfScope pf(PC_FINALIZE, (hipStream_t)stream);
     hipLaunchKernelGGL(topk_finalize_kernel<true>, dim3((unsigned)nq), dim3(256), P2 * sizeof(u64), (hipStream_t)stream,
                        (const u64 *)nullptr, d_parts_d, d_parts_i, n_parts, nq, m, P2, k, (int64_t)0, d_out_d, d_out_i);
     return check_launch("ance_topk_merge");

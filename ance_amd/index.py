@@ -1,0 +1,121 @@
+"""``FlatIPIndex`` -- MI355X replacement for ``faiss.IndexFlatIP`` with the same call shape
+(seam B5): ``idx = FlatIPIndex(d); idx.add(x); D, I = idx.search(q, k)``.
+
+Call sites it replaces: drivers/run_ann_data_gen.py:269-276,303 and
+drivers/run_ann_data_gen_dpr.py:238-252.  The corpus lives in HBM as fp32 [n, d]; search is the
+hand-written fp32-MFMA scan + fused top-k of csrc/ip_topk.hip through the C ABI ``ance_ip_topk``.
+Results follow the canonical order (score desc, row id asc), ``I = -1`` / ``D = -FLT_MAX`` when
+fewer than k rows exist (faiss' convention).  There is no CPU fallback.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+
+
+class FlatIPIndex:
+    def __init__(self, d, device=None, row_base=0):
+        import torch
+        self.d = int(d)
+        self.dp = (self.d + 3) // 4 * 4  # kernel needs d % 4 == 0; zero padding keeps scores exact
+        self.device = torch.device(device if device is not None else "cuda")
+        self.row_base = int(row_base)
+        self._parts = []
+        self._x = None
+        self._ws = None
+
+    # -- faiss-like surface ---------------------------------------------------------------------
+    @property
+    def ntotal(self):
+        return sum(p.shape[0] for p in self._parts)
+
+    def reset(self):
+        self._parts, self._x = [], None
+
+    def _to_device(self, a, what):
+        import torch
+        if isinstance(a, np.ndarray):
+            if a.ndim != 2 or a.shape[1] != self.d:
+                raise ValueError("%s must be [n, %d]" % (what, self.d))
+            t = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(self.device)
+        elif isinstance(a, torch.Tensor):
+            if a.dim() != 2 or a.shape[1] != self.d:
+                raise ValueError("%s must be [n, %d]" % (what, self.d))
+            t = a.to(device=self.device, dtype=torch.float32).contiguous()
+        else:
+            raise TypeError("%s must be a numpy array or torch tensor" % what)
+        if self.dp != self.d:
+            t = torch.nn.functional.pad(t, (0, self.dp - self.d)).contiguous()
+        return t
+
+    def add(self, x):
+        """Append rows.  A contiguous fp32 CUDA tensor is kept by reference (zero copy) -- this is
+        how embeddings stay in the HBM of the GPU that encoded them."""
+        self._parts.append(self._to_device(x, "x"))
+        self._x = None
+
+    def _matrix(self):
+        import torch
+        if self._x is None:
+            if not self._parts:
+                self._x = torch.zeros((0, self.dp), dtype=torch.float32, device=self.device)
+            elif len(self._parts) == 1:
+                self._x = self._parts[0]
+            else:
+                self._x = torch.cat(self._parts, dim=0)
+                self._parts = [self._x]
+        return self._x
+
+    def search(self, q, k):
+        """(D float32 [nq,k], I int64 [nq,k]); numpy in -> numpy out, torch in -> CUDA tensors out."""
+        import torch
+        as_numpy = isinstance(q, np.ndarray)
+        D, I = self.search_device(self._to_device(q, "q"), int(k))
+        if as_numpy:
+            torch.cuda.synchronize(self.device)
+            return D.cpu().numpy(), I.cpu().numpy()
+        return D, I
+
+    # -- device-resident path -------------------------------------------------------------------
+    def search_device(self, qd, k):
+        import torch
+        L = _lib.lib()
+        x = self._matrix()
+        n, nq = x.shape[0], qd.shape[0]
+        D = torch.empty((nq, k), dtype=torch.float32, device=self.device)
+        I = torch.empty((nq, k), dtype=torch.int64, device=self.device)
+        if nq == 0:
+            return D, I
+        need = L.ance_ip_topk_workspace_bytes(n, nq, k)
+        if need == 0:
+            raise _lib.AnceLibraryError("ance_ip_topk: unsupported (n=%d, nq=%d, k=%d)" % (n, nq, k))
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = None
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        with torch.cuda.device(self.device):
+            rc = L.ance_ip_topk(ctypes.c_void_p(x.data_ptr() if n else 0), n, self.row_base,
+                                ctypes.c_void_p(qd.data_ptr()), nq, self.dp, k,
+                                ctypes.c_void_p(D.data_ptr()), ctypes.c_void_p(I.data_ptr()),
+                                ctypes.c_void_p(self._ws.data_ptr()), self._ws.numel(), _lib.current_stream_ptr())
+        _lib.check(rc, "ance_ip_topk")
+        return D, I
+
+
+def topk_merge_device(D_parts, I_parts):
+    """Merge canonical lists [P, nq, k] (CUDA tensors) -> ([nq, k], [nq, k]) via ``ance_topk_merge``."""
+    import torch
+    L = _lib.lib()
+    D_parts = _lib.require_cuda_tensor(D_parts, torch.float32, "D_parts")
+    I_parts = _lib.require_cuda_tensor(I_parts, torch.int64, "I_parts")
+    P, nq, k = D_parts.shape
+    D = torch.empty((nq, k), dtype=torch.float32, device=D_parts.device)
+    I = torch.empty((nq, k), dtype=torch.int64, device=D_parts.device)
+    if nq == 0:
+        return D, I
+    with torch.cuda.device(D_parts.device):
+        rc = L.ance_topk_merge(ctypes.c_void_p(D_parts.data_ptr()), ctypes.c_void_p(I_parts.data_ptr()), P, nq, k,
+                               ctypes.c_void_p(D.data_ptr()), ctypes.c_void_p(I.data_ptr()), None, 0,
+                               _lib.current_stream_ptr())
+    _lib.check(rc, "ance_topk_merge")
+    return D, I

@@ -1,0 +1,276 @@
+#!/usr/bin/env python
+"""Benchmark of the ANN refresh hot path on MI355X (BASELINE.json metric:
+passages-encoded/sec + top-200 queries/sec, 8.8M x 768-d MS MARCO shape, 1/2/4/8 GPU).
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over one batch of synthetic input, timed per leg:
+  encode leg : every rank encodes --encode-block passages (token ids ~ config 2 of SURVEY.md 8d:
+               lengths lognormal(median 70, sigma .45) clipped to [8,128], random-init roberta-base
+               rdot_nll, records already resident in HBM) -> value = passages/s over all ranks;
+  search leg : --query-block queries, exact IP top-200 against the 8,841,823 x 768 fp32 corpus that
+               is resident in HBM, sharded over the ranks (contiguous row blocks), per-shard lists
+               all-gathered over RCCL and merged -> queries/s.
+Both legs: W untimed warm-up steps, then exactly K steps between barrier + synchronize on both
+sides, MAX over ranks.  Rank 0 prints ONE JSON line.  `roofline` comes from HIP events the library
+records around every kernel launch on the launch stream during the timed steps; `cpu_baseline` is
+the oracle (a port of the reference CPU path) timed on this box's host cores on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+N_PASSAGES = 8841823
+N_TRAIN_QUERIES = 502939
+PEAK_F16_TF = 2500.0   # dense fp16/bf16 MFMA, MI355X_MICROARCH.md chip-level table
+PEAK_F32_TF = 157.3    # fp32-input MFMA (= fp32 vector peak)
+PEAK_HBM_GBS = 8000.0
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=5)
+    p.add_argument("--warmup", type=int, default=2)
+    p.add_argument("--encode-block", type=int, default=16384, help="passages per rank per encode step")
+    p.add_argument("--query-block", type=int, default=4096, help="queries per search step")
+    p.add_argument("--n-passages", type=int, default=N_PASSAGES, help="rows of the resident corpus (all ranks)")
+    p.add_argument("--seq-len", type=int, default=128)
+    p.add_argument("--topk", type=int, default=200)
+    p.add_argument("--max-tokens", type=int, default=32768)
+    p.add_argument("--layers", type=int, default=12)
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-seconds", type=float, default=12.0, help="time budget per CPU-baseline leg")
+    p.add_argument("--skip-search", action="store_true")
+    p.add_argument("--skip-encode", action="store_true")
+    return p.parse_args()
+
+
+def timed_steps(fn, steps, warmup, dist_on, torch):
+    for _ in range(warmup):
+        fn()
+    if dist_on:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    if dist_on:
+        torch.distributed.barrier()
+    dt = time.perf_counter() - t0
+    if dist_on:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt
+
+
+def cpu_encode_baseline(seq_len, seconds, layers):
+    """Reference CPU path, encode: fp32 torch on all host cores, batch 16 (the recipe's
+    --per_gpu_eval_batch_size), padded to seq_len like the reference pads."""
+    import torch
+    from oracle import encoder_ref, synth
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    sd = encoder_ref.random_state_dict(seed=0, n_layers=layers)
+    rng = np.random.default_rng(1234)
+    lens = synth.lognormal_lengths(rng, 16, 70, 0.45, 8, seq_len)
+    ids = torch.from_numpy(synth.make_records(rng, 16, seq_len, lens))
+    mask = encoder_ref.mask_from_lengths(lens, seq_len)
+    with torch.no_grad():
+        encoder_ref.rdot_nll_ln_emb(sd, ids, mask, n_layers=layers)  # warm-up
+        n, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < seconds:
+            encoder_ref.rdot_nll_ln_emb(sd, ids, mask, n_layers=layers)
+            n += 16
+        dt = time.perf_counter() - t0
+    return dict(value=n / dt, unit="passages/s", cores=cores, kind="port",
+                sample="%d passages, batch 16 x %d tokens (padded), fp32 torch CPU, oracle/encoder_ref.py" % (n, seq_len))
+
+
+def cpu_search_baseline(n_rows_total, k, seconds):
+    """Reference CPU path, search: BLAS sgemm + selection (what faiss-cpu IndexFlatIP does), on a
+    bounded slice, extrapolated linearly in corpus rows."""
+    from oracle import search_ref, synth
+    cores = os.cpu_count() or 1
+    rng = np.random.default_rng(4321)
+    n_s, nq_s = 200000, 256
+    x = synth.ln_rows(rng, n_s)
+    q = synth.ln_rows(rng, nq_s)
+    search_ref.flat_ip_topk_blas(x[:20000], q[:32], k)
+    done, t0 = 0, time.perf_counter()
+    while True:
+        search_ref.flat_ip_topk_blas(x, q, k)
+        done += nq_s
+        if time.perf_counter() - t0 > seconds:
+            break
+    dt = time.perf_counter() - t0
+    qps_sample = done / dt
+    return dict(value=qps_sample * n_s / n_rows_total, unit="queries/s", cores=cores, kind="port",
+                sample="%d queries x %d rows (sgemm + canonical top-%d, oracle/search_ref.py), scaled by rows to %d"
+                       % (done, n_s, k, n_rows_total))
+
+
+def main():
+    a = parse()
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist_on = world > 1
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if dist_on:
+        torch.distributed.init_process_group(backend="nccl", device_id=dev)
+    from ance_amd import _lib
+    from ance_amd import ann_data_gen as adg
+    from ance_amd.cache import shard_range
+    from ance_amd.encoder import ARCH_ROBERTA, Encoder
+    from oracle import encoder_ref, synth  # weight init + synthetic token ids only (not on the timed path)
+    dist = adg.Dist()
+    eng = adg.HipEngine(dev)
+    errors = {}
+    out = {"metric": "passages_encoded_per_sec", "value": None, "unit": "passages/s", "n_gpus": world,
+           "steps": a.steps, "warmup": a.warmup, "ms_per_step": None, "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+           "config": {"workload": "MS MARCO passage %d x 768-d, roberta-base rdot_nll FirstP seq_len=%d, encode + "
+                                  "brute-force IP top-%d (BASELINE configs[1])" % (a.n_passages, a.seq_len, a.topk),
+                      "encode_block_per_gpu": a.encode_block, "query_block": a.query_block, "layers": a.layers,
+                      "parallelism": "dp%d (corpus rows sharded, top-k all-gather + merge)" % world}}
+
+    # ------------------------------------------------------------------------------ encode leg --
+    if not a.skip_encode:
+        try:
+            sd = encoder_ref.random_state_dict(seed=0, n_layers=a.layers)
+            enc = Encoder(sd, ARCH_ROBERTA, "roberta.", True, max_seq_len=min(a.seq_len, 512),
+                          max_tokens=a.max_tokens, device=dev)
+            del sd
+            rng = np.random.default_rng(1234 + rank)
+            lens = synth.lognormal_lengths(rng, a.encode_block, 70, 0.45, 8, a.seq_len).astype(np.int32)
+            ids = synth.make_records(rng, a.encode_block, a.seq_len, lens.astype(np.int64))
+            rec = np.empty((a.encode_block, 1 + a.seq_len), dtype=np.int32)
+            rec[:, 0] = lens.astype(">u4").view(np.int32)
+            rec[:, 1:] = ids
+            rec_d = torch.from_numpy(rec).to(dev)
+            emb = torch.empty((a.encode_block, 768), dtype=torch.float32, device=dev)
+            flops_alg = float(sum(169869312.0 * t + 36864.0 * t * t + 1179648.0 for t in lens.astype(np.float64)))
+            flops_pad = a.encode_block * (169869312.0 * a.seq_len + 36864.0 * a.seq_len ** 2 + 1179648.0)
+
+            def step_enc():
+                enc.encode_records(rec_d, h_lens=lens, out=emb)
+
+            for _ in range(max(a.warmup, 1)):
+                step_enc()
+            torch.cuda.synchronize()
+            _lib.profile_enable(True)
+            dt = timed_steps(step_enc, a.steps, 0, dist_on, torch)
+            prof = _lib.profile_read()
+            _lib.profile_enable(False)
+            pps = world * a.encode_block * a.steps / dt
+            out["value"] = pps
+            out["ms_per_step"] = 1e3 * dt / a.steps
+            gemm_cats = ["gemm_qk", "gemm_vt", "gemm_attn_out", "gemm_ffn1", "gemm_ffn2"]
+            dom = max(gemm_cats, key=lambda c: prof[c]["ms"])
+            by_kernel = {c: dict(ms_per_launch=(v["ms"] / v["count"]) if v["count"] else None, launches=v["count"],
+                                 total_ms=v["ms"], tflops=(v["work"] / (v["ms"] * 1e-3) / 1e12) if v["ms"] > 0 and v["work"] > 0 else None)
+                         for c, v in prof.items() if v["count"]}
+            ach = prof[dom]["work"] / (prof[dom]["ms"] * 1e-3) / 1e12 if prof[dom]["ms"] > 0 else None
+            all_gemm_ms = sum(prof[c]["ms"] for c in gemm_cats)
+            all_gemm_work = sum(prof[c]["work"] for c in gemm_cats)
+            out["roofline"] = {"bound": "mfma", "kernel": "gemm_f16_kernel (%s)" % dom, "achieved": ach, "peak": PEAK_F16_TF,
+                               "unit": "TFLOP/s", "frac": (ach / PEAK_F16_TF) if ach else None, "traffic": None,
+                               "all_gemm_tflops": all_gemm_work / (all_gemm_ms * 1e-3) / 1e12 if all_gemm_ms > 0 else None,
+                               "by_kernel": by_kernel}
+            out["encode"] = {"passages_per_sec": pps, "tokens_per_sec": pps * float(lens.mean()),
+                             "mean_len": float(lens.mean()),
+                             "algorithmic_tflops": world * flops_alg * a.steps / dt / 1e12,
+                             "padded_equiv_tflops": world * flops_pad * a.steps / dt / 1e12,
+                             "end_to_end_mfma_frac": world * flops_alg * a.steps / dt / 1e12 / (PEAK_F16_TF * world),
+                             "hbm_min_bytes_per_passage": 4 + 4 * a.seq_len + 3072,
+                             "full_corpus_seconds_est": N_PASSAGES / pps}
+            del enc, rec_d, emb
+            torch.cuda.empty_cache()
+        except Exception as e:  # keep going: a bench line with the other leg is still informative
+            import traceback
+            traceback.print_exc()
+            errors["encode"] = repr(e)
+
+    # ------------------------------------------------------------------------------ search leg --
+    if not a.skip_search:
+        try:
+            r0, r1 = shard_range(a.n_passages, rank, world)
+            n_loc = r1 - r0
+            g = torch.Generator(device=dev).manual_seed(4321 + rank)
+            x = torch.empty((n_loc, 768), dtype=torch.float32, device=dev)
+            for b0 in range(0, n_loc, 1 << 20):
+                b1 = min(b0 + (1 << 20), n_loc)
+                z = torch.randn((b1 - b0, 768), generator=g, device=dev)
+                x[b0:b1] = torch.nn.functional.layer_norm(z, (768,))
+            gq = torch.Generator(device=dev).manual_seed(99)
+            q = torch.nn.functional.layer_norm(torch.randn((a.query_block, 768), generator=gq, device=dev), (768,))
+            res = {}
+
+            def step_search():
+                res["DI"] = adg.sharded_search(eng, dist, x, r0, q, a.topk)
+
+            for _ in range(max(a.warmup, 1)):
+                step_search()
+            torch.cuda.synchronize()
+            _lib.profile_enable(True)
+            dt = timed_steps(step_search, a.steps, 0, dist_on, torch)
+            prof = _lib.profile_read()
+            _lib.profile_enable(False)
+            qps = a.query_block * a.steps / dt
+            scan = prof["ip_topk_scan"]
+            ach = scan["work"] / (scan["ms"] * 1e-3) / 1e12 if scan["ms"] > 0 else None
+            D, I = res["DI"]
+            ok = bool((D[:, 1:] <= D[:, :-1]).all().item()) and bool((I >= 0).all().item())
+            out["search"] = {"metric": "top%d_queries_per_sec" % a.topk, "value": qps, "unit": "queries/s",
+                             "ms_per_step": 1e3 * dt / a.steps, "dtype": "f32", "scaling": "strong (corpus sharded)",
+                             "rows_total": a.n_passages, "rows_per_gpu": n_loc, "sorted_and_valid": ok,
+                             "full_train_queries_seconds_est": N_TRAIN_QUERIES / qps,
+                             "roofline": {"bound": "mfma", "kernel": "ip_topk_scan_kernel (fp32 MFMA 32x32x2)",
+                                          "achieved": ach, "peak": PEAK_F32_TF, "unit": "TFLOP/s",
+                                          "frac": (ach / PEAK_F32_TF) if ach else None, "traffic": None,
+                                          "ms_per_launch": scan["ms"] / scan["count"] if scan["count"] else None,
+                                          "finalize_ms_per_launch": prof["topk_finalize"]["ms"] / max(prof["topk_finalize"]["count"], 1),
+                                          "hbm_read_gbs_min": ((n_loc * 768 * 4.0) / (scan["ms"] / max(scan["count"], 1) * 1e-3) / 1e9)
+                                          if scan["ms"] > 0 else None}}
+            del x, q
+        except Exception as e:
+            import traceback
+            traceback.print_exc()
+            errors["search"] = repr(e)
+
+    # ---------------------------------------------------------------------------- CPU baseline --
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        try:
+            if not a.skip_encode:
+                out["cpu_baseline"] = cpu_encode_baseline(a.seq_len, a.cpu_seconds, a.layers)
+            if not a.skip_search and "search" in out:
+                out["search"]["cpu_baseline"] = cpu_search_baseline(a.n_passages, a.topk, a.cpu_seconds)
+        except Exception as e:
+            errors["cpu_baseline"] = repr(e)
+    if errors:
+        out["errors"] = errors
+    if dist_on:
+        torch.distributed.barrier()
+    if rank == 0:
+        print(json.dumps(out))
+    if dist_on:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

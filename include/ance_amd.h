@@ -43,6 +43,19 @@ int ance_abi_version(void);
 /* last HIP error string seen by this library on the calling thread ("" if none) */
 const char *ance_last_error(void);
 
+/*
+ * Measurement hook (bench.py's roofline): when enabled, every kernel launch of this library is
+ * bracketed by HIP events on the launch stream.  ance_profile_read synchronises those events and
+ * returns, per category, the summed kernel time (ms), the summed algorithmic work (FLOP) and the
+ * launch count, then keeps accumulating.  Categories, in order:
+ *   0 plan/pack  1 embed+LN  2 gemm Q|K  3 gemm V^T  4 attention  5 gemm attn-out  6 LayerNorm
+ *   7 gemm FFN1+GELU  8 gemm FFN2  9 head  10 ip_topk scan  11 top-k finalize/merge
+ * Returns the number of categories.  Not thread safe; off by default (no events are created).
+ */
+#define ANCE_PROFILE_CATEGORIES 12
+void ance_profile_enable(int on);
+int ance_profile_read(double *ms, double *work, long long *count, int n);
+
 /* ------------------------------------------------------------------ exact IP top-k search -- */
 
 #define ANCE_TOPK_MAX_K 1792

@@ -50,7 +50,7 @@ def write_cache(path, ids, lengths):
 
 def make_msmarco_like(out_dir, n_passages=10000, n_train=1000, n_dev=200, L=128, Lq=64,
                       seed=1234, dup_frac=0.01, len_median=70, len_sigma=0.45,
-                      q_median=9, q_sigma=0.35):
+                      q_median=9, q_sigma=0.35, plant_frac=0.5):
     """Config-1-style toy set.  Returns a dict of the arrays written."""
     os.makedirs(out_dir, exist_ok=True)
     rng = np.random.default_rng(seed)
@@ -63,7 +63,6 @@ def make_msmarco_like(out_dir, n_passages=10000, n_train=1000, n_dev=200, L=128,
         dst = rng.integers(0, n_passages, size=n_dup)
         pids[dst] = pids[src]
         plen[dst] = plen[src]
-    write_cache(os.path.join(out_dir, "passages"), pids, plen)
 
     def queries(n):
         ql = lognormal_lengths(rng, n, q_median, q_sigma, 4, Lq)
@@ -75,6 +74,14 @@ def make_msmarco_like(out_dir, n_passages=10000, n_train=1000, n_dev=200, L=128,
     write_cache(os.path.join(out_dir, "dev-query"), dq, dql)
 
     train_pos = rng.integers(0, n_passages, size=n_train)
+    # planted hits: for a fraction of the queries the positive passage carries the query's own
+    # tokens, so it is retrieved at rank 1 by any encoder (non-zero NDCG / positive-filter coverage)
+    if plant_frac > 0 and Lq <= L:
+        for q in range(int(plant_frac * n_train)):
+            p = int(train_pos[q])
+            pids[p, :] = PAD
+            pids[p, :Lq] = tq[q]
+            plen[p] = tql[q]
     with open(os.path.join(out_dir, "train-qrel.tsv"), "w") as f:
         for q, p in enumerate(train_pos):
             f.write("%d\t%d\t1\n" % (q, p))
@@ -83,9 +90,15 @@ def make_msmarco_like(out_dir, n_passages=10000, n_train=1000, n_dev=200, L=128,
         for q in range(n_dev):
             m = int(rng.integers(1, 4))
             ps = rng.choice(n_passages, size=m, replace=False)
+            if plant_frac > 0 and Lq <= L and q < int(plant_frac * n_dev):
+                p = int(ps[0])
+                pids[p, :] = PAD
+                pids[p, :Lq] = dq[q]
+                plen[p] = dql[q]
             for p in ps:
                 f.write("%d\t%d\t1\n" % (q, p))
                 dev_rel.append((q, int(p), 1))
+    write_cache(os.path.join(out_dir, "passages"), pids, plen)
     return dict(passages=pids, passage_len=plen, train_query=tq, train_query_len=tql,
                 dev_query=dq, dev_query_len=dql, train_pos=train_pos, dev_rel=dev_rel)
 

@@ -1,0 +1,157 @@
+"""Generates the golden vectors under tests/golden/ by running the REAL reference
+(/root/reference, imported through oracle/ref_harness.py) in the build container.
+
+    python tests/golden/make_golden.py
+
+The reference ships no tests or fixtures of its own, so these vectors are what
+pins the oracle: they are outputs of the reference's own classes / functions on seeded inputs.
+Weights are not stored (a RoBERTa embedding table is 154 MB): they are regenerated from
+``oracle.encoder_ref.random_state_dict(seed)`` and a checksum in the fixture detects an RNG drift.
+"""
+import json
+import os
+import random
+import sys
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+
+from oracle import ann_ref, encoder_ref, ref_harness, synth  # noqa: E402
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def sd_checksum(sd):
+    keys = sorted(sd.keys())
+    return float(sum(sd[k].double().abs().sum().item() for k in keys[:: max(1, len(keys) // 16)]))
+
+
+def load_into(model, sd):
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    bad = [k for k in missing if not (k.startswith("classifier.") or "pooler" in k or "position_ids" in k)]
+    assert not bad and not unexpected, (bad, unexpected)
+
+
+def golden_encoder():
+    rng = np.random.default_rng(2024)
+    out = {}
+    # FirstP / query encoder (model/models.py:149-157), 2 layers, non-trivial LN/bias parameters
+    sd = encoder_ref.random_state_dict(seed=11, n_layers=2, ln_jitter=0.1)
+    m = ref_harness.build_reference_model("rdot_nll", n_layers=2, seed=0)
+    load_into(m, sd)
+    L = 128
+    lens = np.array([1, 2, 8, 31, 32, 33, 64, 70, 100, 127, 128, 128, 5, 17, 96, 77], dtype=np.int32)
+    ids = synth.make_records(rng, len(lens), L, lens.astype(np.int64))
+    with torch.no_grad():
+        emb = m.body_emb(torch.from_numpy(ids).long(), encoder_ref.mask_from_lengths(lens, L))
+    out["firstp"] = dict(seed=11, n_layers=2, ln_jitter=0.1, checksum=sd_checksum(sd))
+    np.savez_compressed(os.path.join(OUT, "encoder_firstp.npz"), ids=ids, lens=lens, emb=emb.numpy())
+
+    # MaxP body encoder (model/models.py:165-199): 4 x 512 chunks incl. all-pad chunks
+    sd2 = encoder_ref.random_state_dict(seed=12, n_layers=1, ln_jitter=0.05)
+    m2 = ref_harness.build_reference_model("rdot_nll_multi_chunk", n_layers=1, seed=0)
+    load_into(m2, sd2)
+    lens2 = np.array([2048, 1500, 513, 512, 40, 1025], dtype=np.int32)
+    ids2 = synth.make_records(rng, len(lens2), 2048, lens2.astype(np.int64))
+    with torch.no_grad():
+        emb2 = m2.body_emb(torch.from_numpy(ids2).long(), encoder_ref.mask_from_lengths(lens2, 2048))
+    out["maxp"] = dict(seed=12, n_layers=1, ln_jitter=0.05, checksum=sd_checksum(sd2))
+    np.savez_compressed(os.path.join(OUT, "encoder_maxp.npz"), ids=ids2, lens=lens2, emb=emb2.numpy())
+
+    # DPR / BERT tower (model/models.py:223-259): raw [CLS]
+    sd3 = encoder_ref.random_state_dict(kind="bert", seed=13, n_layers=2, vocab=30522, max_pos=512, head=False,
+                                        prefixes=("ctx_model.",), ln_jitter=0.1)
+    m3 = ref_harness.build_reference_model("bert", n_layers=2, seed=0)
+    load_into(m3, {k[len("ctx_model."):]: v for k, v in sd3.items()})
+    lens3 = np.array([256, 3, 100, 255, 64, 17, 1, 200], dtype=np.int32)
+    ids3 = rng.integers(1000, 30522, size=(len(lens3), 256)).astype(np.int32)
+    ids3[:, 0] = 101
+    ids3[np.arange(len(lens3)), lens3 - 1] = 102
+    ids3[:, 0] = 101
+    ids3 = np.where(np.arange(256)[None, :] < lens3[:, None], ids3, 0).astype(np.int32)
+    with torch.no_grad():
+        t = torch.from_numpy(ids3).long()
+        emb3 = m3(t, (t != 0).long())[1]
+    out["bert"] = dict(seed=13, n_layers=2, ln_jitter=0.1, checksum=sd_checksum(sd3))
+    np.savez_compressed(os.path.join(OUT, "encoder_bert.npz"), ids=ids3, lens=lens3, emb=emb3.numpy())
+    return out
+
+
+def golden_postsearch():
+    """GenerateNegativePassaageID / EvalDevQuery of the reference on seeded neighbour lists."""
+    ref = ref_harness.load_reference()
+    G = ref.driver
+    rng = np.random.default_rng(7)
+    n_rows, chunks, nq, k = 4000, 4, 60, 50
+    p2id = (np.arange(n_rows) // chunks).astype(np.int64)  # MaxP-style: several rows per pid
+    q2id = np.arange(100, 100 + nq, dtype=np.int64)
+    I = np.stack([rng.choice(n_rows, size=k, replace=False) for _ in range(nq)]).astype(np.int64)
+    train_pos = {int(q): int(p2id[I[i, rng.integers(0, 12)]]) for i, q in enumerate(q2id)}
+    eff = set(q2id.tolist())
+    cases = {}
+    for topk in (False, True):
+        args = types.SimpleNamespace(ann_measure_topk_mrr=topk, negative_sample=7, rank=0)
+        random.seed(123)
+        neg = G.GenerateNegativePassaageID(args, q2id, p2id, train_pos, I, eff)
+        cases["neg_topk%d" % int(topk)] = {str(kk): [int(v) for v in vv] for kk, vv in neg.items()}
+    dev_q2id = np.arange(nq, dtype=np.int64)
+    dev_pos = {}
+    for i in range(nq):
+        rel = {}
+        for j in rng.choice(60, size=int(rng.integers(1, 4)), replace=False):
+            pid = int(p2id[I[i, j]]) if j < k else int(rng.integers(0, n_rows // chunks))
+            rel[pid] = int(rng.integers(1, 3))
+        dev_pos[i] = rel
+    args = types.SimpleNamespace(rank=0)
+    ndcg, cnt = G.EvalDevQuery(args, dev_q2id, p2id, dev_pos, I)
+    np.savez_compressed(os.path.join(OUT, "postsearch.npz"), p2id=p2id, q2id=q2id, I=I)
+    with open(os.path.join(OUT, "postsearch.json"), "w") as f:
+        json.dump(dict(train_pos={str(a): b for a, b in train_pos.items()},
+                       dev_pos={str(a): {str(c): d for c, d in b.items()} for a, b in dev_pos.items()},
+                       cases=cases, ndcg=ndcg, ndcg_cnt=cnt, negative_sample=7, seed=123), f)
+    return dict(ndcg=ndcg, cnt=cnt)
+
+
+def golden_end_to_end():
+    """The reference's own generate_new_ann on a toy set, CPU, 2-layer model."""
+    import shutil
+    import tempfile
+    tmp = tempfile.mkdtemp(prefix="ance_golden_")
+    try:
+        data = os.path.join(tmp, "data")
+        synth.make_msmarco_like(data, n_passages=400, n_train=60, n_dev=20, L=64, Lq=32, seed=77)
+        sd = encoder_ref.random_state_dict(seed=21, n_layers=2, ln_jitter=0.1)
+        m = ref_harness.build_reference_model("rdot_nll", n_layers=2, seed=0)
+        load_into(m, sd)
+        outd = os.path.join(tmp, "out")
+        res = ref_harness.run_generate_new_ann(data, outd, m, output_num=0, checkpoint_path="/x/checkpoint-100/",
+                                               step=100, seed=5, max_seq_length=64, max_query_length=32,
+                                               topk_training=40, negative_sample=6, ann_chunk_factor=2,
+                                               ann_measure_topk_mrr=True)
+        with open(os.path.join(outd, "ann_training_data_0")) as f:
+            lines = f.read()
+        with open(os.path.join(outd, "ann_ndcg_0")) as f:
+            nd = json.load(f)
+        with open(os.path.join(OUT, "e2e_toy.json"), "w") as f:
+            json.dump(dict(weights=dict(seed=21, n_layers=2, ln_jitter=0.1, checksum=sd_checksum(sd)),
+                           data=dict(n_passages=400, n_train=60, n_dev=20, L=64, Lq=32, seed=77),
+                           args=dict(max_seq_length=64, max_query_length=32, topk_training=40, negative_sample=6,
+                                     ann_chunk_factor=2, ann_measure_topk_mrr=True, seed=5, output_num=0,
+                                     checkpoint_path="/x/checkpoint-100/"),
+                           ann_training_data_0=lines, ann_ndcg_0=nd, result=[res[0], res[1]]), f)
+        return dict(ndcg=nd["ndcg"], lines=lines.count("\n"))
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(8)
+    info = dict(encoder=golden_encoder(), postsearch=golden_postsearch(), e2e=golden_end_to_end(),
+                torch=torch.__version__, numpy=np.__version__)
+    with open(os.path.join(OUT, "manifest.json"), "w") as f:
+        json.dump(info, f, indent=1)
+    print(json.dumps(info, indent=1))

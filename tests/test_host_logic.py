@@ -1,0 +1,163 @@
+"""Host-side product logic (ance_amd.negatives / cache / ann_data_gen helpers) against the golden
+vectors of the reference and against the oracle restatement -- CPU only, no kernel calls."""
+import json
+import os
+import random
+import types
+
+import numpy as np
+import pytest
+
+from ance_amd import ann_data_gen as adg
+from ance_amd import negatives
+from ance_amd.cache import TokenCache, shard_range
+from oracle import ann_ref, synth
+
+
+def _postsearch(golden_dir):
+    g = np.load(os.path.join(golden_dir, "postsearch.npz"))
+    with open(os.path.join(golden_dir, "postsearch.json")) as f:
+        j = json.load(f)
+    train_pos = {int(k): v for k, v in j["train_pos"].items()}
+    dev_pos = {int(k): {int(a): b for a, b in v.items()} for k, v in j["dev_pos"].items()}
+    return g, j, train_pos, dev_pos
+
+
+@pytest.mark.parametrize("topk", [False, True])
+def test_negatives_match_reference_golden(golden_dir, topk, capsys):
+    g, j, train_pos, _ = _postsearch(golden_dir)
+    random.seed(j["seed"])
+    neg = negatives.generate_negative_passage_ids(g["q2id"], g["p2id"], train_pos, g["I"], set(g["q2id"].tolist()),
+                                                  j["negative_sample"], topk)
+    want = {int(k): v for k, v in j["cases"]["neg_topk%d" % int(topk)].items()}
+    assert neg == want
+    if topk:
+        assert "ANN MRR:" in capsys.readouterr().out
+
+
+def test_dev_ndcg_matches_reference_golden(golden_dir):
+    g, j, _, dev_pos = _postsearch(golden_dir)
+    ndcg, cnt = negatives.eval_dev_query(np.arange(g["I"].shape[0]), g["p2id"], dev_pos, g["I"])
+    assert cnt == j["ndcg_cnt"] and abs(ndcg - j["ndcg"]) < 1e-12
+
+
+def test_negatives_and_ndcg_match_oracle_randomised():
+    rng = np.random.default_rng(99)
+    for trial in range(5):
+        n_rows, chunks, nq, k = 900, int(rng.integers(1, 4)), 40, 30
+        p2id = np.arange(n_rows) // chunks
+        q2id = rng.permutation(200)[:nq]
+        I = np.stack([rng.choice(n_rows, size=k, replace=False) for _ in range(nq)])
+        pos = {int(q): int(p2id[I[i, rng.integers(0, k)]]) if rng.random() < 0.7 else int(rng.integers(0, 300))
+               for i, q in enumerate(q2id)}
+        eff = set(q2id[: nq - 3].tolist())
+        for topk in (False, True):
+            random.seed(trial)
+            a = negatives.generate_negative_passage_ids(q2id, p2id, pos, I, eff, 5, topk, verbose=False)
+            random.seed(trial)
+            b, _ = ann_ref.generate_negative_passage_ids(q2id, p2id, pos, I, eff, 5, topk)
+            assert a == {int(k_): [int(x) for x in v] for k_, v in b.items()}
+        dev = {int(q): {int(p2id[I[i, j]]): int(rng.integers(1, 4)) for j in rng.choice(k, 2, replace=False)}
+               for i, q in enumerate(q2id) if i % 5}
+        x = negatives.eval_dev_query(q2id, p2id, dev, I)
+        y = ann_ref.eval_dev_query(q2id, p2id, dev, I)
+        assert x[1] == y[1] and abs(x[0] - y[0]) < 1e-12
+
+
+def test_query_chunk_matches_reference_rule():
+    for nq in (0, 1, 7, 100, 502939):
+        for cf in (1, 2, 5, 7):
+            for out_num in range(0, 9):
+                assert negatives.query_chunk(nq, out_num, cf) == ann_ref.query_chunk(nq, out_num, cf)
+    with pytest.raises(ZeroDivisionError):
+        negatives.query_chunk(10, 0, 0)
+    # chunks tile the query set
+    covered = []
+    for out_num in range(5):
+        s, e = negatives.query_chunk(103, out_num, 5)
+        covered += list(range(s, e))
+    assert covered == list(range(103))
+
+
+def test_token_cache_roundtrip(tmp_path):
+    rng = np.random.default_rng(5)
+    lens = np.array([0, 1, 7, 16, 3], dtype=np.int64)
+    ids = synth.make_records(rng, 5, 16, lens)
+    path = str(tmp_path / "passages")
+    synth.write_cache(path, ids, lens)
+    c = TokenCache(path)
+    assert len(c) == 5 and c.record_size == 4 + 64
+    with c as cc:
+        assert np.array_equal(cc.lengths(), lens)
+        assert np.array_equal(cc.ids(), ids)
+        pl, p = cc[2]
+        assert pl == 7 and np.array_equal(p, ids[2])
+        raw = cc.records(1, 3)
+        assert raw.shape == (2, 68) and bytes(raw[1, :4]) == (7).to_bytes(4, "big")
+    # oracle reader agrees
+    l2, i2 = ann_ref.read_cache(path)
+    assert np.array_equal(l2, lens) and np.array_equal(i2, ids)
+    with pytest.raises(IndexError):
+        with TokenCache(path) as cc:
+            cc[99]
+
+
+def test_shard_range_partitions():
+    for n in (0, 1, 7, 8, 9, 8841823):
+        for w in (1, 2, 3, 8):
+            parts = [shard_range(n, r, w) for r in range(w)]
+            assert parts[0][0] == 0 and parts[-1][1] == n
+            for a, b in zip(parts, parts[1:]):
+                assert a[1] == b[0]
+
+
+def test_latest_ann_data_and_checkpoint(tmp_path):
+    out = tmp_path / "ann"
+    assert adg.get_latest_ann_data(str(out)) == (-1, None, None)
+    out.mkdir()
+    assert adg.get_latest_ann_data(str(out)) == (-1, None, None)
+    for n in (0, 3, 12):
+        (out / ("ann_ndcg_%d" % n)).write_text(json.dumps({"ndcg": 0.1 * n, "checkpoint": "/m/checkpoint-%d/" % (n * 100)}))
+        (out / ("ann_training_data_%d" % n)).write_text("1\t2\t3,4\n")
+    no, path, js = adg.get_latest_ann_data(str(out))
+    assert no == 12 and path.endswith("ann_training_data_12") and js["checkpoint"].endswith("1200/")
+    assert (no, path, js) == ann_ref.get_latest_ann_data(str(out))
+    assert adg.get_checkpoint_no(js["checkpoint"]) == 1200 == ann_ref.get_checkpoint_no(js["checkpoint"])
+
+    tr = tmp_path / "train"
+    args = types.SimpleNamespace(training_dir=str(tr), init_model_dir="/init")
+    assert adg.get_latest_checkpoint(args) == ("/init", 0)
+    tr.mkdir()
+    (tr / "checkpoint-100").mkdir()
+    (tr / "checkpoint-100" / "scheduler.pt").write_text("x")
+    (tr / "checkpoint-300").mkdir()  # no commit marker yet: must be ignored
+    path, step = adg.get_latest_checkpoint(args)
+    assert step == 100 and path == os.path.join(str(tr), "checkpoint-100") + "/"
+
+
+def test_writers_respect_contract(tmp_path):
+    q2id = np.array([5, 6, 7, 8])
+    pos = {5: 50, 6: 60, 8: 80}
+    neg = {5: [1, 2], 6: [3], 7: [9], 8: [4, 5, 6]}
+    random.seed(3)
+    train_path, ndcg_path = negatives.write_ann_files(str(tmp_path), 2, 4, q2id, {5, 6, 7, 8}, pos, neg, 0.25,
+                                                      "/m/checkpoint-400/")
+    lines = open(train_path).read().splitlines()
+    assert sorted(lines) == sorted(["5\t50\t1,2", "6\t60\t3", "8\t80\t4,5,6"])  # 7 has no positive
+    assert json.load(open(ndcg_path)) == {"ndcg": 0.25, "checkpoint": "/m/checkpoint-400/"}
+    # identical to the oracle's restatement under the same seed
+    d2 = tmp_path / "o"
+    d2.mkdir()
+    random.seed(3)
+    ann_ref.write_ann_files(str(d2), 2, np.zeros((4, 1)), q2id, {5, 6, 7, 8}, pos, neg, 0.25, "/m/checkpoint-400/")
+    assert open(train_path).read() == (d2 / "ann_training_data_2").read_text()
+    assert adg.get_latest_ann_data(str(tmp_path))[0] == 2
+
+
+def test_cli_flags_match_reference_names():
+    a = adg.get_arguments(["--data_dir", "d", "--training_dir", "t", "--init_model_dir", "i", "--model_type", "rdot_nll",
+                           "--output_dir", "o", "--cache_dir", "c", "--topk_training", "200", "--negative_sample", "20",
+                           "--end_output_num", "0", "--ann_measure_topk_mrr", "--inference", "--local_rank", "3"])
+    assert (a.topk_training, a.negative_sample, a.end_output_num, a.ann_chunk_factor) == (200, 20, 0, 5)
+    assert a.max_seq_length == 128 and a.max_query_length == 64 and a.per_gpu_eval_batch_size == 128
+    assert a.ann_measure_topk_mrr and a.inference and a.local_rank == 3 and not a.only_keep_latest_embedding_file
