@@ -56,6 +56,55 @@ def parse():
     return p.parse_args()
 
 
+def synthetic_records(rng, n, L):
+    """Tokenised-cache rows [n, 1+L] int32 (big-endian length header, <s> ... </s>, pad = 1) with the
+    length distribution of SURVEY.md 8d config 2.  Returns (records, lengths)."""
+    lens = np.clip(np.rint(rng.lognormal(np.log(70.0), 0.45, size=n)), 8, L).astype(np.int32)
+    ids = rng.integers(3, 50265, size=(n, L), dtype=np.int64).astype(np.int32)
+    ids[:, 0] = 0
+    ids[np.arange(n), lens - 1] = 2
+    ids = np.where(np.arange(L)[None, :] < lens[:, None], ids, 1).astype(np.int32)
+    rec = np.empty((n, 1 + L), dtype=np.int32)
+    rec[:, 0] = lens.astype(">u4").view(np.int32)
+    rec[:, 1:] = ids
+    return rec, lens
+
+
+def random_init_roberta_base(torch, n_layers, seed=0):
+    """Random-init rdot_nll weights (normal std 0.02 / LayerNorm 1,0 / bias 0 -- the reference's
+    _init_weights, model/models.py:31-36); there are no checkpoints offline."""
+    g = torch.Generator().manual_seed(seed)
+    H, I = 768, 3072
+    sd = {}
+
+    def lin(name, o, i):
+        sd[name + ".weight"] = torch.randn(o, i, generator=g) * 0.02
+        sd[name + ".bias"] = torch.zeros(o)
+
+    def ln(name):
+        sd[name + ".weight"] = torch.ones(H)
+        sd[name + ".bias"] = torch.zeros(H)
+
+    e = "roberta.embeddings."
+    sd[e + "word_embeddings.weight"] = torch.randn(50265, H, generator=g) * 0.02
+    sd[e + "position_embeddings.weight"] = torch.randn(514, H, generator=g) * 0.02
+    sd[e + "token_type_embeddings.weight"] = torch.randn(1, H, generator=g) * 0.02
+    ln(e + "LayerNorm")
+    for i in range(n_layers):
+        p = "roberta.encoder.layer.%d." % i
+        lin(p + "attention.self.query", H, H)
+        lin(p + "attention.self.key", H, H)
+        lin(p + "attention.self.value", H, H)
+        lin(p + "attention.output.dense", H, H)
+        ln(p + "attention.output.LayerNorm")
+        lin(p + "intermediate.dense", I, H)
+        lin(p + "output.dense", H, I)
+        ln(p + "output.LayerNorm")
+    lin("embeddingHead", 768, H)
+    ln("norm")
+    return sd
+
+
 def timed_steps(fn, steps, warmup, dist_on, torch):
     for _ in range(warmup):
         fn()
@@ -137,7 +186,6 @@ def main():
     from ance_amd import ann_data_gen as adg
     from ance_amd.cache import shard_range
     from ance_amd.encoder import ARCH_ROBERTA, Encoder
-    from oracle import encoder_ref, synth  # weight init + synthetic token ids only (not on the timed path)
     dist = adg.Dist()
     eng = adg.HipEngine(dev)
     errors = {}
@@ -152,16 +200,12 @@ def main():
     # ------------------------------------------------------------------------------ encode leg --
     if not a.skip_encode:
         try:
-            sd = encoder_ref.random_state_dict(seed=0, n_layers=a.layers)
+            sd = random_init_roberta_base(torch, a.layers, seed=0)
             enc = Encoder(sd, ARCH_ROBERTA, "roberta.", True, max_seq_len=min(a.seq_len, 512),
                           max_tokens=a.max_tokens, device=dev)
             del sd
             rng = np.random.default_rng(1234 + rank)
-            lens = synth.lognormal_lengths(rng, a.encode_block, 70, 0.45, 8, a.seq_len).astype(np.int32)
-            ids = synth.make_records(rng, a.encode_block, a.seq_len, lens.astype(np.int64))
-            rec = np.empty((a.encode_block, 1 + a.seq_len), dtype=np.int32)
-            rec[:, 0] = lens.astype(">u4").view(np.int32)
-            rec[:, 1:] = ids
+            rec, lens = synthetic_records(rng, a.encode_block, a.seq_len)
             rec_d = torch.from_numpy(rec).to(dev)
             emb = torch.empty((a.encode_block, 768), dtype=torch.float32, device=dev)
             flops_alg = float(sum(169869312.0 * t + 36864.0 * t * t + 1179648.0 for t in lens.astype(np.float64)))
