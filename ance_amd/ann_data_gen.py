@@ -217,7 +217,7 @@ def generate_new_ann(args, output_num, checkpoint_path, training_query_positive_
     if model is None:
         from .encoder import load_model
         model = load_model(args.model_type, checkpoint_path, max_seq_length=args.max_seq_length,
-                           max_tokens=getattr(args, "max_tokens", 32768), device=getattr(args, "device", None))
+                           max_tokens=getattr(args, "max_tokens", 65536), device=getattr(args, "device", None))
     chunks = getattr(model, "chunks", 1)
 
     logger.info("***** inference of dev query *****")
@@ -348,7 +348,7 @@ def get_arguments(argv=None):
     p.add_argument("--config_name", default="", type=str)
     p.add_argument("--tokenizer_name", default="", type=str)
     # additions (not in the reference)
-    p.add_argument("--max_tokens", default=32768, type=int, help="tokens per encoder micro-batch")
+    p.add_argument("--max_tokens", default=65536, type=int, help="tokens per encoder micro-batch")
     p.add_argument("--seed", default=None, type=int, help="seed `random` before negative sampling")
     return p.parse_args(argv)
 

@@ -322,7 +322,7 @@ namespace {
 bool desc_ok(const AnceEncoderDesc *d) {
     return d && d->hidden == H && d->n_heads == 12 && d->intermediate > 0 && d->intermediate % 128 == 0 &&
            d->n_layers >= 1 && d->vocab_size > 0 && d->max_position > 0 && d->max_seq_len >= 1 &&
-           d->max_seq_len <= 512 && d->max_tokens >= 512 && d->max_tokens % 128 == 0 &&
+           d->max_seq_len <= 512 && d->max_tokens >= 512 && d->max_tokens % 256 == 0 &&
            (d->arch == ANCE_ARCH_ROBERTA || d->arch == ANCE_ARCH_BERT);
 }
 
@@ -364,7 +364,7 @@ void layout_weights(const AnceEncoderDesc *d, Arena &a, AnceEncoder *e) {
 void layout_workspace(const AnceEncoderDesc *d, Arena &a, AnceEncoder *e) {
     const int tcap = d->max_tokens;
     const int scap = tcap < S_CAP_MAX ? tcap : S_CAP_MAX;
-    const int vcap = (int)align_up((size_t)tcap + tcap / 4 + 128, 128);
+    const int vcap = (int)align_up((size_t)tcap + tcap / 4 + 256, 256);
     int *seq_off = a.take<int>(scap + 1), *seq_vtcol = a.take<int>(scap), *seq_len = a.take<int>(scap);
     int *tok_id = a.take<int>(tcap), *tok_pos = a.take<int>(tcap), *tok_vtcol = a.take<int>(tcap);
     int *lens_fetch = a.take<int>(FETCH_CHUNK);
@@ -435,7 +435,7 @@ int encode_impl(AnceEncoder *e, const int32_t *base, int64_t ld, const int32_t *
                 lc = lc < 0 ? 0 : (lc > Lc ? Lc : lc);
                 const int eff = lc > 0 ? lc : 1;
                 const int v8 = (eff + 7) & ~7;
-                if (T + eff > e->tcap || V + v8 > e->vcap - 128) break;
+                if (T + eff > e->tcap || V + v8 > e->vcap - 256) break;
                 T += eff; V += v8; ++S; ++g;
                 if (eff > maxlen) maxlen = eff;
             }
@@ -443,8 +443,8 @@ int encode_impl(AnceEncoder *e, const int32_t *base, int64_t ld, const int32_t *
                 set_last_error("ance_encode: max_tokens too small for one sequence");
                 return ANCE_E_INVALID;
             }
-            const int Tpad = (int)align_up((size_t)T, 128);
-            const int ldvt = (int)align_up((size_t)V, 128);
+            const int Tpad = (int)align_up((size_t)T, 256);
+            const int ldvt = (int)align_up((size_t)V, 256);
 
             PlanArgs P;
             P.base = base; P.ld = ld; P.lens = d_lens; P.hdr = hdr;

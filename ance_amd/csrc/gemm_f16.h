@@ -22,6 +22,11 @@ struct GemmArgs {
     int n_valid;         // EPI_VT: columns n >= n_valid are not stored
 };
 
+// Dispatcher: 256 x 256 tile kernel (gemm256_f16.hip) when the shape allows, else the 128 x 128 one.
+// ANCE_GEMM=128|256reg|256glds overrides the choice (A/B measurements).
 int launch_gemm_f16(int epi, const GemmArgs &args, hipStream_t stream);
+int launch_gemm128_f16(int epi, const GemmArgs &args, hipStream_t stream);
+bool gemm256_applicable(const GemmArgs &args);
+int launch_gemm256_f16(int epi, const GemmArgs &args, bool glds, hipStream_t stream);
 
 }  // namespace ance

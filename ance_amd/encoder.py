@@ -59,7 +59,7 @@ class Encoder:
     """One transformer tower + (optional) ANCE head resident in HBM."""
 
     def __init__(self, state_dict, arch=ARCH_ROBERTA, prefix="roberta.", has_head=True, pad_token_id=None,
-                 ln_eps=None, max_seq_len=512, max_tokens=32768, device=None):
+                 ln_eps=None, max_seq_len=512, max_tokens=65536, device=None):
         import torch
         L = _lib.lib()
         self.device = torch.device(device if device is not None else "cuda")
@@ -80,7 +80,7 @@ class Encoder:
             pad_token_id=(1 if arch == ARCH_ROBERTA else 0) if pad_token_id is None else int(pad_token_id),
             ln_eps=(1e-5 if arch == ARCH_ROBERTA else 1e-12) if ln_eps is None else float(ln_eps),
             has_head=1 if has_head else 0, max_seq_len=int(max_seq_len),
-            max_tokens=int(max_tokens) // 128 * 128)
+            max_tokens=max(512, int(max_tokens) // 256 * 256))
         wbytes = L.ance_encoder_weight_bytes(ctypes.byref(self.desc))
         xbytes = L.ance_encoder_workspace_bytes(ctypes.byref(self.desc))
         if wbytes == 0 or xbytes == 0:
@@ -203,7 +203,7 @@ def load_hf_state_dict(ckpt_dir):
     raise FileNotFoundError("no model.safetensors / pytorch_model.bin in %s" % ckpt_dir)
 
 
-def load_model(model_type, checkpoint_path, max_seq_length=128, max_tokens=32768, device=None):
+def load_model(model_type, checkpoint_path, max_seq_length=128, max_tokens=65536, device=None):
     """Registry of model/models.py:299-322 restricted to the encoders on the path."""
     model_type = model_type.lower()
     if model_type in ("rdot_nll", "rdot_nll_multi_chunk"):

@@ -1,0 +1,22 @@
+#!/bin/bash
+# rocprofv3 on the torch-free ABI probe: kernel-trace stats + PMC (HBM bytes) in separate runs.
+set -u
+cd "$(dirname "$0")/.."
+mkdir -p gpurun_out/pmc
+export TMPDIR=/tmp
+export LD_LIBRARY_PATH=/opt/rocm/lib:${LD_LIBRARY_PATH:-}
+S="tools/abi_probe search ${PMC_N:-2000000} ${PMC_NQ:-4096} 200 2"
+E="tools/abi_probe encode ${PMC_NP:-4096} 128 12 2 65536"
+echo "== plain runs"; timeout 300 $S; timeout 300 $E
+for what in search encode; do
+  cmd="$S"; [ $what = encode ] && cmd="$E"
+  echo "== kernel-trace $what"
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/pmc/kt_$what -o kt -- $cmd > gpurun_out/pmc/kt_$what.log 2>&1; echo "rc=$?"
+  for c in FETCH_SIZE WRITE_SIZE; do
+    echo "== pmc $c $what"
+    timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmc/${c}_$what -o pmc -- $cmd > gpurun_out/pmc/${c}_$what.log 2>&1; echo "rc=$?"
+    tail -3 gpurun_out/pmc/${c}_$what.log | cut -c1-200
+  done
+done
+find gpurun_out/pmc -name "*.csv" | head -30
+python scripts/summarize_pmc.py gpurun_out/pmc 2>&1 | head -60
