@@ -12,6 +12,7 @@ struct AttnArgs {
     const int *seq_vtcol;  // [n_seq] first (8-aligned) V^T column of each sequence
     int ld_qk, ld_vt, ld_ctx;
     int n_heads;
+    int cls_only;          // 1: only query 0 of every sequence is computed; its row goes to ctx[s] (compact)
 };
 
 size_t attention_lds_bytes(int max_seq_len);

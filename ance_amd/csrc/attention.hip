@@ -67,7 +67,9 @@ __global__ void __launch_bounds__(ATT_THREADS) attention_kernel(const AttnArgs A
     __syncthreads();
 
     const int nkb = Tk >> 5;
-    for (int qb0 = w * 32; qb0 < T; qb0 += 128) {
+    // cls_only (last layer): only the [CLS] query feeds the head, so one wave does one 32-query block
+    const int q_end = A.cls_only ? 1 : T;
+    for (int qb0 = w * 32; qb0 < q_end; qb0 += 128) {
         // Q fragment (B operand): lane (query i, group g) holds head dims 32 g + 8 s .. + 8, s = 0..3
         const int qrow = min(qb0 + i, T - 1);
         const _Float16 *qp = A.qk + (size_t)(tok0 + qrow) * A.ld_qk + h * HD + 32 * g;
@@ -135,8 +137,9 @@ __global__ void __launch_bounds__(ATT_THREADS) attention_kernel(const AttnArgs A
         const float l_tot = l_run + __shfl_xor(l_run, 32);
         const float inv = 1.0f / l_tot;
         // O^T[d][query]: d = db*32 + (r&3) + 8 (r>>2) + 4 g  ->  4 consecutive d per (db, r>>2)
-        if (qb0 + i < T) {
-            _Float16 *op = A.ctx + (size_t)(tok0 + qb0 + i) * A.ld_ctx + h * HD + 4 * g;
+        if (qb0 + i < q_end) {
+            const size_t orow = A.cls_only ? (size_t)s : (size_t)(tok0 + qb0 + i);
+            _Float16 *op = A.ctx + orow * A.ld_ctx + h * HD + 4 * g;
 #pragma unroll
             for (int db = 0; db < 2; ++db) {
                 const f32x16 &o = db == 0 ? o0 : o1;

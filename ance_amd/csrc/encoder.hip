@@ -233,14 +233,31 @@ __global__ void __launch_bounds__(256) ln_kernel(const float *pre, int Tpad, con
     ln_row_store(x4[l], x4[64 + l], x4[128 + l], gamma, beta, eps, h32 + (size_t)t * H, h16 + (size_t)t * H, l);
 }
 
+// last layer, CLS-only tail: compact residual rows  dst[s] = h32[seq_off[s]]  (rows S..S_pad zeroed)
+__global__ void __launch_bounds__(256) gather_cls_kernel(const float *h32, const int *seq_off, int S, int S_pad, float *dst) {
+    const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int l = threadIdx.x & 63;
+    if (s >= S_pad) return;
+    f32x4 *d4 = reinterpret_cast<f32x4 *>(dst + (size_t)s * H);
+    if (s < S) {
+        const f32x4 *s4 = reinterpret_cast<const f32x4 *>(h32 + (size_t)seq_off[s] * H);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) d4[k * 64 + l] = s4[k * 64 + l];
+    } else {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) d4[k * 64 + l] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+}
+
 // head: emb = LayerNorm_768(W h_cls + b) (model/models.py:152-153), or raw h_cls (models.py:239)
-__global__ void __launch_bounds__(256) head_kernel(const float *h32, const int *seq_off, const float *W, const float *b,
-                                                   const float *gamma, const float *beta, int has_head, float *out) {
+__global__ void __launch_bounds__(256) head_kernel(const float *h32, const int *seq_off, int compact, const float *W,
+                                                   const float *b, const float *gamma, const float *beta, int has_head,
+                                                   float *out) {
     __shared__ float cls[H];
     __shared__ float z[HEAD_OUT];
     __shared__ float red[8];
     const int s = blockIdx.x, tid = threadIdx.x;
-    const float *src = h32 + (size_t)seq_off[s] * H;
+    const float *src = h32 + (size_t)(compact ? s : seq_off[s]) * H;  // compact: row s already is the [CLS] row
     float *dst = out + (size_t)s * HEAD_OUT;
     if (!has_head) {
         for (int j = tid; j < H; j += 256) dst[j] = src[j];
@@ -315,6 +332,7 @@ struct AnceEncoder {
     float *h32, *pre32;
     _Float16 *h16, *qk16, *vt16, *ctx16, *ffn16;
     std::vector<int32_t> host_lens;
+    bool cls_tail;  // run the last layer's post-attention part on the [CLS] rows only (ANCE_CLS_TAIL=0 disables)
 };
 
 namespace {
@@ -463,8 +481,15 @@ int encode_impl(AnceEncoder *e, const int32_t *base, int64_t ld, const int32_t *
             hipLaunchKernelGGL(embed_ln_kernel, dim3(Tpad / 4), dim3(256), 0, st, e->tok_id, e->tok_pos, Tpad, e->word, e->pos,
                                e->type0, D.vocab_size, D.max_position, e->eln_w, e->eln_b, D.ln_eps, e->h32, e->h16);
             }
+            // Only the [CLS] row of the last layer reaches the head (model/models.py:49,152): after the
+            // last layer's K / V projections everything runs on the S compact [CLS] rows.
+            const bool cls_tail = e->cls_tail;
+            const int S_pad = (int)align_up((size_t)S, 256);
             for (int li = 0; li < D.n_layers; ++li) {
                 const LayerW &W = e->layers[li];
+                const bool tail = cls_tail && li == D.n_layers - 1;
+                const int Mrows = tail ? S_pad : Tpad;   // rows of the post-attention GEMMs / LayerNorms
+                const double Mwork = tail ? (double)S : (double)T;
                 GemmArgs G;
                 memset(&G, 0, sizeof(G));
                 // Q | K projection
@@ -487,54 +512,61 @@ int encode_impl(AnceEncoder *e, const int32_t *base, int64_t ld, const int32_t *
                 if (rc) return rc;
                 AttnArgs A;
                 A.qk = e->qk16; A.vt = e->vt16; A.ctx = e->ctx16; A.seq_off = e->seq_off; A.seq_vtcol = e->seq_vtcol;
-                A.ld_qk = 2 * H; A.ld_vt = ldvt; A.ld_ctx = H; A.n_heads = D.n_heads;
+                A.ld_qk = 2 * H; A.ld_vt = ldvt; A.ld_ctx = H; A.n_heads = D.n_heads; A.cls_only = tail ? 1 : 0;
                 {
                     ProfScope ps(PC_ATTN, st, 0.0);
                     rc = launch_attention(A, S, maxlen, st);
                 }
                 if (rc) return rc;
                 // attention.output.dense + residual
+                const float *resid = e->h32;
+                if (tail) {  // compact residual rows, parked in the (currently dead) FFN buffer
+                    float *rc = reinterpret_cast<float *>(e->ffn16);
+                    ProfScope ps(PC_LN, st);
+                    hipLaunchKernelGGL(gather_cls_kernel, dim3(S_pad / 4), dim3(256), 0, st, e->h32, e->seq_off, S, S_pad, rc);
+                    resid = rc;
+                }
                 memset(&G, 0, sizeof(G));
-                G.A = e->ctx16; G.lda = H; G.B = W.wo; G.ldb = H; G.M = Tpad; G.N = H; G.K = H;
-                G.bias = W.bo; G.out32 = e->pre32; G.res32 = e->h32; G.ldc = H;
+                G.A = e->ctx16; G.lda = H; G.B = W.wo; G.ldb = H; G.M = Mrows; G.N = H; G.K = H;
+                G.bias = W.bo; G.out32 = e->pre32; G.res32 = resid; G.ldc = H;
                 {
-                    ProfScope ps(PC_GEMM_OUT, st, 2.0 * T * (double)H * H);
+                    ProfScope ps(PC_GEMM_OUT, st, 2.0 * Mwork * (double)H * H);
                     rc = launch_gemm_f16(EPI_RES32, G, st);
                 }
                 if (rc) return rc;
                 {
                     ProfScope ps(PC_LN, st);
-                    hipLaunchKernelGGL(ln_kernel, dim3(Tpad / 4), dim3(256), 0, st, e->pre32, Tpad, W.ln1w, W.ln1b, D.ln_eps,
+                    hipLaunchKernelGGL(ln_kernel, dim3(Mrows / 4), dim3(256), 0, st, e->pre32, Mrows, W.ln1w, W.ln1b, D.ln_eps,
                                        e->h32, e->h16);
                 }
                 // intermediate.dense + GELU
                 memset(&G, 0, sizeof(G));
-                G.A = e->h16; G.lda = H; G.B = W.w1; G.ldb = H; G.M = Tpad; G.N = I; G.K = H;
+                G.A = e->h16; G.lda = H; G.B = W.w1; G.ldb = H; G.M = Mrows; G.N = I; G.K = H;
                 G.bias = W.b1; G.out16 = e->ffn16; G.ldc = I;
                 {
-                    ProfScope ps(PC_GEMM_FFN1, st, 2.0 * T * (double)I * H);
+                    ProfScope ps(PC_GEMM_FFN1, st, 2.0 * Mwork * (double)I * H);
                     rc = launch_gemm_f16(EPI_GELU, G, st);
                 }
                 if (rc) return rc;
                 // output.dense + residual
                 memset(&G, 0, sizeof(G));
-                G.A = e->ffn16; G.lda = I; G.B = W.w2; G.ldb = I; G.M = Tpad; G.N = H; G.K = I;
+                G.A = e->ffn16; G.lda = I; G.B = W.w2; G.ldb = I; G.M = Mrows; G.N = H; G.K = I;
                 G.bias = W.b2; G.out32 = e->pre32; G.res32 = e->h32; G.ldc = H;
                 {
-                    ProfScope ps(PC_GEMM_FFN2, st, 2.0 * T * (double)I * H);
+                    ProfScope ps(PC_GEMM_FFN2, st, 2.0 * Mwork * (double)I * H);
                     rc = launch_gemm_f16(EPI_RES32, G, st);
                 }
                 if (rc) return rc;
                 {
                     ProfScope ps(PC_LN, st);
-                    hipLaunchKernelGGL(ln_kernel, dim3(Tpad / 4), dim3(256), 0, st, e->pre32, Tpad, W.ln2w, W.ln2b, D.ln_eps,
+                    hipLaunchKernelGGL(ln_kernel, dim3(Mrows / 4), dim3(256), 0, st, e->pre32, Mrows, W.ln2w, W.ln2b, D.ln_eps,
                                        e->h32, e->h16);
                 }
             }
             {
                 ProfScope ps(PC_HEAD, st);
-                hipLaunchKernelGGL(head_kernel, dim3(S), dim3(256), 0, st, e->h32, e->seq_off, e->head_w, e->head_b, e->norm_w,
-                                   e->norm_b, D.has_head, d_out + (size_t)(r0 * n_chunks + gs) * HEAD_OUT);
+                hipLaunchKernelGGL(head_kernel, dim3(S), dim3(256), 0, st, e->h32, e->seq_off, cls_tail ? 1 : 0, e->head_w, e->head_b,
+                                   e->norm_w, e->norm_b, D.has_head, d_out + (size_t)(r0 * n_chunks + gs) * HEAD_OUT);
             }
             gs = g;
         }
@@ -578,6 +610,10 @@ extern "C" int ance_encoder_create(const AnceEncoderDesc *desc, const void *cons
     AnceEncoder *e = new (std::nothrow) AnceEncoder();
     if (!e) return ANCE_E_NOMEM;
     e->d = *desc;
+    {
+        const char *ct = getenv("ANCE_CLS_TAIL");
+        e->cls_tail = !(ct && ct[0] == '0');
+    }
     Arena wa, xa;
     wa.base = reinterpret_cast<char *>(align_up((uintptr_t)d_weight_arena, 256));
     xa.base = reinterpret_cast<char *>(align_up((uintptr_t)d_workspace, 256));

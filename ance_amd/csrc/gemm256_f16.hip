@@ -149,19 +149,26 @@ __global__ void __launch_bounds__(G256_THREADS, 2) gemm256_f16_kernel(const Gemm
         if (kt + 1 < NK) stage_issue(kt + 1, buf ^ 1);
         const _Float16 *sa = smem + buf * STAGE_HALVES;  // A-matrix rows (m)
         const _Float16 *sb = sa + OPER_HALVES;           // B-matrix rows (n)
+        // fragments of k-step s+1 are requested before the MFMAs of k-step s are issued
+        f16x8 fn[2][2], fm[2][4];
+        auto load_frags = [&](int s, int set) {
+            const int ch = 2 * s + g;
+#pragma unroll
+            for (int x = 0; x < 2; ++x)
+                fn[set][x] = *reinterpret_cast<const f16x8 *>(sb + nrow[x] * TK + ((ch ^ nsw[x]) * 8));
+#pragma unroll
+            for (int y = 0; y < 4; ++y)
+                fm[set][y] = *reinterpret_cast<const f16x8 *>(sa + mrow[y] * TK + ((ch ^ msw[y]) * 8));
+        };
+        load_frags(0, 0);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            const int ch = 2 * s + g;
-            f16x8 fn[2], fm[4];
-#pragma unroll
-            for (int x = 0; x < 2; ++x) fn[x] = *reinterpret_cast<const f16x8 *>(sb + nrow[x] * TK + ((ch ^ nsw[x]) * 8));
-#pragma unroll
-            for (int y = 0; y < 4; ++y) fm[y] = *reinterpret_cast<const f16x8 *>(sa + mrow[y] * TK + ((ch ^ msw[y]) * 8));
+            if (s + 1 < 4) load_frags(s + 1, (s + 1) & 1);
 #pragma unroll
             for (int x = 0; x < 2; ++x)
 #pragma unroll
                 for (int y = 0; y < 4; ++y)
-                    acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fn[x], fm[y], acc[x][y], 0, 0, 0);
+                    acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fn[s & 1][x], fm[s & 1][y], acc[x][y], 0, 0, 0);
         }
         if (kt + 1 < NK) {
             if constexpr (GLDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -174,32 +181,38 @@ __global__ void __launch_bounds__(G256_THREADS, 2) gemm256_f16_kernel(const Gemm
     // acc[x][y][r]: n = n0 + wn*64 + x*32 + (r&3) + 8*(r>>2) + 4*g ;  m = m0 + wm*128 + y*32 + i
     const int mw0 = m0 + wm * 128, nw0 = n0 + wn * 64;
     if constexpr (EPI == EPI_VT) {
-        // rows of the output are A-matrix rows m (features), columns are tokens n scattered through
-        // col_map; the lane owns feature m and 4 consecutive tokens per register quad.
+        // Output rows are A-matrix rows m (features, bias per row); columns are tokens n scattered
+        // through col_map (per-sequence 8-aligned key columns, so 16-byte stores are impossible in
+        // general).  Slab [64 m][64 n] halves per pass; on read-back a lane owns ONE token column and
+        // walks the 64 feature rows: every store instruction writes 64 consecutive tokens = 128 B of
+        // one V^T row, and col_map is read once per lane.
+        _Float16 *slab = smem + w * 8192;
+        constexpr int LS = 72;
+        const int ntok = nw0 + l;
+        const bool tok_ok = ntok < G.n_valid;
+        const int col = tok_ok ? G.col_map[ntok] : 0;
 #pragma unroll
-        for (int y = 0; y < 4; ++y) {
-            const int m = mw0 + y * 32 + i;
-            const float bias = G.bias[m];
-            _Float16 *orow = G.out16 + (size_t)m * G.ldc;
+        for (int p = 0; p < 2; ++p) {
+            __syncthreads();
 #pragma unroll
-            for (int x = 0; x < 2; ++x)
+            for (int yy = 0; yy < 2; ++yy) {
+                const float bias = G.bias[mw0 + (2 * p + yy) * 32 + i];
 #pragma unroll
-                for (int rq = 0; rq < 4; ++rq) {
-                    const int n = nw0 + x * 32 + 8 * rq + 4 * g;
-                    if (n >= G.n_valid) continue;
-                    const int c0 = G.col_map[n];
-                    const bool contig = (n + 3 < G.n_valid) && (G.col_map[n + 3] == c0 + 3) && ((c0 & 3) == 0);
-                    const f32x16 &a = acc[x][y];
-                    if (contig) {
-                        *reinterpret_cast<f16x4 *>(orow + c0) =
+                for (int x = 0; x < 2; ++x)
+#pragma unroll
+                    for (int rq = 0; rq < 4; ++rq) {
+                        const f32x16 &a = acc[x][2 * p + yy];
+                        *reinterpret_cast<f16x4 *>(slab + (yy * 32 + i) * LS + x * 32 + 8 * rq + 4 * g) =
                             f16x4{(_Float16)(a[4 * rq] + bias), (_Float16)(a[4 * rq + 1] + bias),
                                   (_Float16)(a[4 * rq + 2] + bias), (_Float16)(a[4 * rq + 3] + bias)};
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            if (n + e < G.n_valid) orow[G.col_map[n + e]] = (_Float16)(a[4 * rq + e] + bias);
                     }
-                }
+            }
+            __syncthreads();
+            if (tok_ok) {
+                _Float16 *obase = G.out16 + (size_t)(mw0 + p * 64) * G.ldc + col;
+#pragma unroll 8
+                for (int rr = 0; rr < 64; ++rr) obase[(size_t)rr * G.ldc] = slab[rr * LS + l];
+            }
         }
     } else if constexpr (EPI == EPI_RES32) {
         // wave-private slab [32 m][64 n] fp32, row stride 68 floats; 4 passes over the wave's 128 rows
