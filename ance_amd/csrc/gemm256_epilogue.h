@@ -1,0 +1,142 @@
+// Shared epilogue of the 256 x 256 fp16 GEMM kernels (gemm256_f16.hip, gemm256r_f16.hip).
+// Swapped MFMA orientation: acc[x][y][r] holds  n = n0 + wn*64 + x*32 + (r&3) + 8*(r>>2) + 4*g,
+// m = m0 + wm*128 + y*32 + i  -- a lane owns one output row m and 4 consecutive n per register
+// quad, staged through a wave-private 16 KiB LDS slab so that global traffic is whole 16-byte row
+// segments.  Must be entered by all 512 threads after the last LDS read of the main loop.
+#pragma once
+#include "common.h"
+#include "gemm_f16.h"
+
+namespace ance {
+
+// GELU(x) = x * Phi(x) with Phi from the Abramowitz-Stegun 7.1.26 erfc polynomial (|abs err| of
+// erf <= 1.5e-7, far below the fp16 resolution of the stored result): ~14 VALU ops instead of the
+// ~30 of ocml's erff, which matters because this epilogue runs on 3072 columns per token with no
+// MFMA work to hide behind.  The erfc form keeps the negative tail free of cancellation.
+__device__ __forceinline__ float gelu_erf256(float x) {
+    const float z = x * 0.70710678118654752440f;
+    const float az = fabsf(z);
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, az, 1.0f));
+    float p = fmaf(t, 1.061405429f, -1.453152027f);
+    p = fmaf(t, p, 1.421413741f);
+    p = fmaf(t, p, -0.284496736f);
+    p = fmaf(t, p, 0.254829592f);
+    const float h = 0.5f * p * t * __expf(-az * az);  // 0.5 * erfc(|z|)
+    return x * (z >= 0.0f ? 1.0f - h : h);
+}
+
+template <int EPI>
+__device__ __forceinline__ void gemm256_epilogue(const GemmArgs &G, f32x16 (&acc)[2][4], float *smem_f, int m0, int n0,
+                                                 int w, int l) {
+    _Float16 *smem = reinterpret_cast<_Float16 *>(smem_f);
+    const int g = l >> 5, i = l & 31;
+    const int wm = w >> 2, wn = w & 3;
+    // acc[x][y][r]: n = n0 + wn*64 + x*32 + (r&3) + 8*(r>>2) + 4*g ;  m = m0 + wm*128 + y*32 + i
+    const int mw0 = m0 + wm * 128, nw0 = n0 + wn * 64;
+    if constexpr (EPI == EPI_VT) {
+        // Output rows are A-matrix rows m (features, bias per row); columns are tokens n scattered
+        // through col_map (per-sequence 8-aligned key columns, so 16-byte stores are impossible in
+        // general).  Slab [64 m][64 n] halves per pass; on read-back a lane owns ONE token column and
+        // walks the 64 feature rows: every store instruction writes 64 consecutive tokens = 128 B of
+        // one V^T row, and col_map is read once per lane.
+        _Float16 *slab = smem + w * 8192;
+        constexpr int LS = 72;
+        const int ntok = nw0 + l;
+        const bool tok_ok = ntok < G.n_valid;
+        const int col = tok_ok ? G.col_map[ntok] : 0;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            __syncthreads();
+#pragma unroll
+            for (int yy = 0; yy < 2; ++yy) {
+                const float bias = G.bias[mw0 + (2 * p + yy) * 32 + i];
+#pragma unroll
+                for (int x = 0; x < 2; ++x)
+#pragma unroll
+                    for (int rq = 0; rq < 4; ++rq) {
+                        const f32x16 &a = acc[x][2 * p + yy];
+                        *reinterpret_cast<f16x4 *>(slab + (yy * 32 + i) * LS + x * 32 + 8 * rq + 4 * g) =
+                            f16x4{(_Float16)(a[4 * rq] + bias), (_Float16)(a[4 * rq + 1] + bias),
+                                  (_Float16)(a[4 * rq + 2] + bias), (_Float16)(a[4 * rq + 3] + bias)};
+                    }
+            }
+            __syncthreads();
+            if (tok_ok) {
+                _Float16 *obase = G.out16 + (size_t)(mw0 + p * 64) * G.ldc + col;
+#pragma unroll 8
+                for (int rr = 0; rr < 64; ++rr) obase[(size_t)rr * G.ldc] = slab[rr * LS + l];
+            }
+        }
+    } else if constexpr (EPI == EPI_RES32) {
+        // wave-private slab [32 m][64 n] fp32, row stride 68 floats; 4 passes over the wave's 128 rows
+        float *slab = smem_f + w * 4096;  // 16 KiB per wave
+        constexpr int LS = 68;
+        const int c4 = l & 15;
+        const f32x4 bias = *reinterpret_cast<const f32x4 *>(G.bias + nw0 + c4 * 4);
+#pragma unroll
+        for (int y = 0; y < 4; ++y) {
+            // residual rows of this pass: issued first so their latency hides behind the LDS round trip
+            f32x4 res[8];
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int rr = it * 4 + (l >> 4);
+                res[it] = *reinterpret_cast<const f32x4 *>(G.res32 + (size_t)(mw0 + y * 32 + rr) * G.ldc + nw0 + c4 * 4);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int x = 0; x < 2; ++x)
+#pragma unroll
+                for (int rq = 0; rq < 4; ++rq) {
+                    const f32x16 &a = acc[x][y];
+                    *reinterpret_cast<f32x4 *>(slab + i * LS + x * 32 + 8 * rq + 4 * g) =
+                        f32x4{a[4 * rq], a[4 * rq + 1], a[4 * rq + 2], a[4 * rq + 3]};
+                }
+            __syncthreads();
+            // read back: 16 lanes cover one row (64 floats), 4 rows per instruction, 8 instructions
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int rr = it * 4 + (l >> 4);
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(slab + rr * LS + c4 * 4);
+                *reinterpret_cast<f32x4 *>(G.out32 + (size_t)(mw0 + y * 32 + rr) * G.ldc + nw0 + c4 * 4) = v + bias + res[it];
+            }
+        }
+    } else {
+        // fp16 outputs: slab [64 m][64 n] halves, row stride 72 halves (144 B); 2 passes
+        _Float16 *slab = smem + w * 8192;  // 16 KiB per wave
+        constexpr int LS = 72;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            __syncthreads();
+#pragma unroll
+            for (int yy = 0; yy < 2; ++yy)
+#pragma unroll
+                for (int x = 0; x < 2; ++x)
+#pragma unroll
+                    for (int rq = 0; rq < 4; ++rq) {
+                        const f32x16 &a = acc[x][2 * p + yy];
+                        const int nl = x * 32 + 8 * rq + 4 * g;  // local n of element 0
+                        const f32x4 bias = *reinterpret_cast<const f32x4 *>(G.bias + nw0 + nl);
+                        f16x4 v;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float t = a[4 * rq + e] + bias[e];
+                            if constexpr (EPI == EPI_GELU) t = gelu_erf256(t);
+                            else t = (nw0 + nl + e) < G.scale_cols ? t * G.scale : t;
+                            v[e] = (_Float16)t;
+                        }
+                        *reinterpret_cast<f16x4 *>(slab + (yy * 32 + i) * LS + nl) = v;
+                    }
+            __syncthreads();
+            // read back: 8 lanes cover one row (64 halves = 128 B), 8 rows per instruction
+            const int c8 = l & 7;
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int rr = it * 8 + (l >> 3);
+                const f16x8 v = *reinterpret_cast<const f16x8 *>(slab + rr * LS + c8 * 8);
+                *reinterpret_cast<f16x8 *>(G.out16 + (size_t)(mw0 + p * 64 + rr) * G.ldc + nw0 + c8 * 8) = v;
+            }
+        }
+    }
+}
+
+}  // namespace ance

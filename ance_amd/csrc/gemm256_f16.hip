@@ -1,5 +1,11 @@
-// 256 x 256 x 64 fp16 MFMA GEMM for the encoder (gfx950), same contract as gemm_f16.hip:
-//   C[m][n] = sum_k A[m][k] * B[n][k],  A [M,K] and B [N,K] row-major f16, fp32 accumulation.
+// 256 x 256 x 64 fp16 MFMA GEMM with fused epilogues for the encoder (gfx950):
+//   C[m][n] = sum_k A[m][k] * B[n][k],  A [M,K] and B [N,K] row-major f16 (nn.Linear weight layout,
+//   so y = x W^T needs no transpose), fp32 accumulation.
+// Epilogues (what the reference computes after each nn.Linear, fused here):
+//   EPI_QK     out16 = (acc + bias[n]) * (n < scale_cols ? scale : 1)      Q | K projection, Q/8
+//   EPI_GELU   out16 = gelu_erf(acc + bias[n])                            intermediate.dense
+//   EPI_RES32  out32 = acc + bias[n] + res32[m][n]                        attention.output.dense / output.dense
+//   EPI_VT     out16[m][col[n]] = acc + bias[m]   (n < n_valid)           V^T = Wv . h^T, key-contiguous
 //
 // Why this tile: a 128 x 128 tile has 64 FLOP per staged byte, i.e. 39 TB/s of L2 traffic at the
 // 2.5 PFLOP/s MFMA rate -- more than the 34.5 TB/s the eight L2s deliver -- so it is L2-bound by
@@ -12,11 +18,16 @@
 // wave-private row-major LDS slab and reads it back as whole 16-byte row segments: global stores
 // (and the residual read) are full-width and coalesced instead of 4-byte scalars.
 //
-// Staging variants (template GLDS): register staged (global_load_dwordx4 -> ds_write_b128) or
-// direct-to-LDS (global_load_lds_dwordx4, the LDS image is lane-linear so the XOR swizzle is
-// applied to the per-lane SOURCE address).  Same LDS image, same reads.
+// Staging is direct-to-LDS (global_load_lds_dwordx4): the LDS image is lane-linear, so the XOR
+// swizzle is applied to the per-lane SOURCE address.  Measured alternatives on MI355X (DESIGN.md
+// section 9): register staging -8%, a 4-slot BK=32 ring with counted vmcnt -4..-8%, staggering the
+// two waves of a SIMD -1..-3%, a depth-2 register pipeline spills (acc 128 + 2 x 32 staging VGPRs).
+// Template ABLATE compiles the ablation switches of ance_debug_gemm in (1: no loads after the first
+// tile, 2: no MFMA, 4: every block loads tile (0,0)); the product instance has none of them.
 #include "common.h"
 #include "gemm_f16.h"
+#include "gemm256_epilogue.h"
+#include <string.h>
 
 namespace ance {
 namespace {
@@ -27,26 +38,10 @@ constexpr int STAGE_HALVES = 2 * OPER_HALVES;   // A-rows tile + B-rows tile (64
 constexpr int G256_THREADS = 512;
 constexpr size_t G256_LDS_BYTES = (size_t)2 * STAGE_HALVES * sizeof(_Float16);  // 128 KiB
 
-// GELU(x) = x * Phi(x) with Phi from the Abramowitz-Stegun 7.1.26 erfc polynomial (|abs err| of
-// erf <= 1.5e-7, far below the fp16 resolution of the stored result): ~14 VALU ops instead of the
-// ~30 of ocml's erff, which matters because this epilogue runs on 3072 columns per token with no
-// MFMA work to hide behind.  The erfc form keeps the negative tail free of cancellation.
-__device__ __forceinline__ float gelu_erf256(float x) {
-    const float z = x * 0.70710678118654752440f;
-    const float az = fabsf(z);
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, az, 1.0f));
-    float p = fmaf(t, 1.061405429f, -1.453152027f);
-    p = fmaf(t, p, 1.421413741f);
-    p = fmaf(t, p, -0.284496736f);
-    p = fmaf(t, p, 0.254829592f);
-    const float h = 0.5f * p * t * __expf(-az * az);  // 0.5 * erfc(|z|)
-    return x * (z >= 0.0f ? 1.0f - h : h);
-}
-
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void glb_void_t;
 
-template <int EPI, bool GLDS>
+template <int EPI, bool ABLATE>
 __global__ void __launch_bounds__(G256_THREADS, 2) gemm256_f16_kernel(const GemmArgs G) {
     extern __shared__ __attribute__((aligned(16))) float smem_f[];
     _Float16 *smem = reinterpret_cast<_Float16 *>(smem_f);
@@ -79,44 +74,23 @@ __global__ void __launch_bounds__(G256_THREADS, 2) gemm256_f16_kernel(const Gemm
     // lane L: row-in-group L >> 3, LDS slot L & 7  ->  source chunk = slot ^ swizzle(row).
     const int rg = l >> 3, slot = l & 7;
     const _Float16 *srcA[4], *srcB[4];
-    int ldsoff[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int row = (j * 8 + w) * 8 + rg;
         const int ch = slot ^ ((row >> 1) & 7);
-        srcA[j] = G.A + (size_t)(m0 + row) * G.lda + ch * 8;
-        srcB[j] = G.B + (size_t)(n0 + row) * G.ldb + ch * 8;
-        ldsoff[j] = row * TK + slot * 8;  // halves; lane-linear within the wave's 1 KiB piece
+        const int ml = (ABLATE && (G.debug_mode & 4)) ? 0 : m0, nl = (ABLATE && (G.debug_mode & 4)) ? 0 : n0;  // ablation: L2-resident operands
+        srcA[j] = G.A + (size_t)(ml + row) * G.lda + ch * 8;
+        srcB[j] = G.B + (size_t)(nl + row) * G.ldb + ch * 8;
     }
-    f16x8 ra[4], rb[4];
     auto stage_issue = [&](int kt, int buf) {
         const int k0 = kt * TK;
-        if constexpr (GLDS) {
-            _Float16 *sa = smem + buf * STAGE_HALVES;
-            _Float16 *sb = sa + OPER_HALVES;
+        _Float16 *sa = smem + buf * STAGE_HALVES;
+        _Float16 *sb = sa + OPER_HALVES;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int piece = ((j * 8 + w) * 8) * TK;  // wave-uniform LDS base of this 1 KiB piece
-                __builtin_amdgcn_global_load_lds((glb_void_t *)(srcA[j] + k0), (lds_void_t *)(sa + piece), 16, 0, 0);
-                __builtin_amdgcn_global_load_lds((glb_void_t *)(srcB[j] + k0), (lds_void_t *)(sb + piece), 16, 0, 0);
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                ra[j] = *reinterpret_cast<const f16x8 *>(srcA[j] + k0);
-                rb[j] = *reinterpret_cast<const f16x8 *>(srcB[j] + k0);
-            }
-        }
-    };
-    auto stage_commit = [&](int buf) {  // register path only
-        if constexpr (!GLDS) {
-            _Float16 *sa = smem + buf * STAGE_HALVES;
-            _Float16 *sb = sa + OPER_HALVES;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                *reinterpret_cast<f16x8 *>(sa + ldsoff[j]) = ra[j];
-                *reinterpret_cast<f16x8 *>(sb + ldsoff[j]) = rb[j];
-            }
+        for (int j = 0; j < 4; ++j) {
+            const int piece = ((j * 8 + w) * 8) * TK;  // wave-uniform LDS base of this 1 KiB piece
+            __builtin_amdgcn_global_load_lds((glb_void_t *)(srcA[j] + k0), (lds_void_t *)(sa + piece), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_void_t *)(srcB[j] + k0), (lds_void_t *)(sb + piece), 16, 0, 0);
         }
     };
 
@@ -141,12 +115,11 @@ __global__ void __launch_bounds__(G256_THREADS, 2) gemm256_f16_kernel(const Gemm
 
     const int NK = G.K / TK;
     stage_issue(0, 0);
-    if constexpr (GLDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    stage_commit(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     for (int kt = 0; kt < NK; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < NK) stage_issue(kt + 1, buf ^ 1);
+        if (kt + 1 < NK && !(ABLATE && (G.debug_mode & 1))) stage_issue(kt + 1, buf ^ 1);
         const _Float16 *sa = smem + buf * STAGE_HALVES;  // A-matrix rows (m)
         const _Float16 *sb = sa + OPER_HALVES;           // B-matrix rows (n)
         // fragments of k-step s+1 are requested before the MFMAs of k-step s are issued
@@ -160,145 +133,47 @@ __global__ void __launch_bounds__(G256_THREADS, 2) gemm256_f16_kernel(const Gemm
             for (int y = 0; y < 4; ++y)
                 fm[set][y] = *reinterpret_cast<const f16x8 *>(sa + mrow[y] * TK + ((ch ^ msw[y]) * 8));
         };
-        load_frags(0, 0);
+        auto mfma_step = [&](int set) {
+            if (ABLATE && (G.debug_mode & 2)) {  // ablation: keep the LDS reads alive, skip the matrix pipe
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            if (s + 1 < 4) load_frags(s + 1, (s + 1) & 1);
+                for (int x = 0; x < 2; ++x) asm volatile("" ::"v"(fn[set][x]));
+#pragma unroll
+                for (int y = 0; y < 4; ++y) asm volatile("" ::"v"(fm[set][y]));
+                return;
+            }
 #pragma unroll
             for (int x = 0; x < 2; ++x)
 #pragma unroll
                 for (int y = 0; y < 4; ++y)
-                    acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fn[s & 1][x], fm[s & 1][y], acc[x][y], 0, 0, 0);
+                    acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fn[set][x], fm[set][y], acc[x][y], 0, 0, 0);
+        };
+        load_frags(0, 0);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            if (s + 1 < 4) load_frags(s + 1, (s + 1) & 1);
+            mfma_step(s & 1);
         }
-        if (kt + 1 < NK) {
-            if constexpr (GLDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            stage_commit(buf ^ 1);
-        }
+        // an LDS-DMA is a pending LDS write on the VM counter: retire it before the barrier publishes it
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
 
-    // ---- epilogue --------------------------------------------------------------------------------
-    // acc[x][y][r]: n = n0 + wn*64 + x*32 + (r&3) + 8*(r>>2) + 4*g ;  m = m0 + wm*128 + y*32 + i
-    const int mw0 = m0 + wm * 128, nw0 = n0 + wn * 64;
-    if constexpr (EPI == EPI_VT) {
-        // Output rows are A-matrix rows m (features, bias per row); columns are tokens n scattered
-        // through col_map (per-sequence 8-aligned key columns, so 16-byte stores are impossible in
-        // general).  Slab [64 m][64 n] halves per pass; on read-back a lane owns ONE token column and
-        // walks the 64 feature rows: every store instruction writes 64 consecutive tokens = 128 B of
-        // one V^T row, and col_map is read once per lane.
-        _Float16 *slab = smem + w * 8192;
-        constexpr int LS = 72;
-        const int ntok = nw0 + l;
-        const bool tok_ok = ntok < G.n_valid;
-        const int col = tok_ok ? G.col_map[ntok] : 0;
-#pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            __syncthreads();
-#pragma unroll
-            for (int yy = 0; yy < 2; ++yy) {
-                const float bias = G.bias[mw0 + (2 * p + yy) * 32 + i];
-#pragma unroll
-                for (int x = 0; x < 2; ++x)
-#pragma unroll
-                    for (int rq = 0; rq < 4; ++rq) {
-                        const f32x16 &a = acc[x][2 * p + yy];
-                        *reinterpret_cast<f16x4 *>(slab + (yy * 32 + i) * LS + x * 32 + 8 * rq + 4 * g) =
-                            f16x4{(_Float16)(a[4 * rq] + bias), (_Float16)(a[4 * rq + 1] + bias),
-                                  (_Float16)(a[4 * rq + 2] + bias), (_Float16)(a[4 * rq + 3] + bias)};
-                    }
-            }
-            __syncthreads();
-            if (tok_ok) {
-                _Float16 *obase = G.out16 + (size_t)(mw0 + p * 64) * G.ldc + col;
-#pragma unroll 8
-                for (int rr = 0; rr < 64; ++rr) obase[(size_t)rr * G.ldc] = slab[rr * LS + l];
-            }
-        }
-    } else if constexpr (EPI == EPI_RES32) {
-        // wave-private slab [32 m][64 n] fp32, row stride 68 floats; 4 passes over the wave's 128 rows
-        float *slab = smem_f + w * 4096;  // 16 KiB per wave
-        constexpr int LS = 68;
-        const int c4 = l & 15;
-        const f32x4 bias = *reinterpret_cast<const f32x4 *>(G.bias + nw0 + c4 * 4);
-#pragma unroll
-        for (int y = 0; y < 4; ++y) {
-            // residual rows of this pass: issued first so their latency hides behind the LDS round trip
-            f32x4 res[8];
-#pragma unroll
-            for (int it = 0; it < 8; ++it) {
-                const int rr = it * 4 + (l >> 4);
-                res[it] = *reinterpret_cast<const f32x4 *>(G.res32 + (size_t)(mw0 + y * 32 + rr) * G.ldc + nw0 + c4 * 4);
-            }
-            __syncthreads();
-#pragma unroll
-            for (int x = 0; x < 2; ++x)
-#pragma unroll
-                for (int rq = 0; rq < 4; ++rq) {
-                    const f32x16 &a = acc[x][y];
-                    *reinterpret_cast<f32x4 *>(slab + i * LS + x * 32 + 8 * rq + 4 * g) =
-                        f32x4{a[4 * rq], a[4 * rq + 1], a[4 * rq + 2], a[4 * rq + 3]};
-                }
-            __syncthreads();
-            // read back: 16 lanes cover one row (64 floats), 4 rows per instruction, 8 instructions
-#pragma unroll
-            for (int it = 0; it < 8; ++it) {
-                const int rr = it * 4 + (l >> 4);
-                const f32x4 v = *reinterpret_cast<const f32x4 *>(slab + rr * LS + c4 * 4);
-                *reinterpret_cast<f32x4 *>(G.out32 + (size_t)(mw0 + y * 32 + rr) * G.ldc + nw0 + c4 * 4) = v + bias + res[it];
-            }
-        }
-    } else {
-        // fp16 outputs: slab [64 m][64 n] halves, row stride 72 halves (144 B); 2 passes
-        _Float16 *slab = smem + w * 8192;  // 16 KiB per wave
-        constexpr int LS = 72;
-#pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            __syncthreads();
-#pragma unroll
-            for (int yy = 0; yy < 2; ++yy)
-#pragma unroll
-                for (int x = 0; x < 2; ++x)
-#pragma unroll
-                    for (int rq = 0; rq < 4; ++rq) {
-                        const f32x16 &a = acc[x][2 * p + yy];
-                        const int nl = x * 32 + 8 * rq + 4 * g;  // local n of element 0
-                        const f32x4 bias = *reinterpret_cast<const f32x4 *>(G.bias + nw0 + nl);
-                        f16x4 v;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            float t = a[4 * rq + e] + bias[e];
-                            if constexpr (EPI == EPI_GELU) t = gelu_erf256(t);
-                            else t = (nw0 + nl + e) < G.scale_cols ? t * G.scale : t;
-                            v[e] = (_Float16)t;
-                        }
-                        *reinterpret_cast<f16x4 *>(slab + (yy * 32 + i) * LS + nl) = v;
-                    }
-            __syncthreads();
-            // read back: 8 lanes cover one row (64 halves = 128 B), 8 rows per instruction
-            const int c8 = l & 7;
-#pragma unroll
-            for (int it = 0; it < 8; ++it) {
-                const int rr = it * 8 + (l >> 3);
-                const f16x8 v = *reinterpret_cast<const f16x8 *>(slab + rr * LS + c8 * 8);
-                *reinterpret_cast<f16x8 *>(G.out16 + (size_t)(mw0 + p * 64 + rr) * G.ldc + nw0 + c8 * 8) = v;
-            }
-        }
-    }
+    gemm256_epilogue<EPI>(G, acc, smem_f, m0, n0, w, l);
 }
 
-template <bool GLDS>
+template <bool ABLATE>
 int launch256(int epi, const GemmArgs &G, hipStream_t st) {
     const int MT = G.M / TM, NT = G.N / TN;
     const unsigned blocks = MT >= NT ? (unsigned)((MT + 7) / 8 * 8) * (unsigned)NT : (unsigned)((NT + 7) / 8 * 8) * (unsigned)MT;
     void (*k)(const GemmArgs) = nullptr;
     switch (epi) {
-        case EPI_QK: k = gemm256_f16_kernel<EPI_QK, GLDS>; break;
-        case EPI_GELU: k = gemm256_f16_kernel<EPI_GELU, GLDS>; break;
-        case EPI_RES32: k = gemm256_f16_kernel<EPI_RES32, GLDS>; break;
-        case EPI_VT: k = gemm256_f16_kernel<EPI_VT, GLDS>; break;
+        case EPI_QK: k = gemm256_f16_kernel<EPI_QK, ABLATE>; break;
+        case EPI_GELU: k = gemm256_f16_kernel<EPI_GELU, ABLATE>; break;
+        case EPI_RES32: k = gemm256_f16_kernel<EPI_RES32, ABLATE>; break;
+        case EPI_VT: k = gemm256_f16_kernel<EPI_VT, ABLATE>; break;
         default: set_last_error("gemm256: bad epilogue"); return ANCE_E_INVALID;
     }
-    static bool attr_done[4] = {false, false, false, false};
+    static bool attr_done[4] = {false, false, false, false};  // per template instance
     if (!attr_done[epi]) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)G256_LDS_BYTES) != hipSuccess)
@@ -315,12 +190,32 @@ bool gemm256_applicable(const GemmArgs &G) {
     return G.M > 0 && G.N > 0 && G.K > 0 && G.M % TM == 0 && G.N % TN == 0 && G.K % TK == 0;
 }
 
-int launch_gemm256_f16(int epi, const GemmArgs &G, bool glds, hipStream_t st) {
+int launch_gemm_f16(int epi, const GemmArgs &G, hipStream_t st) {
     if (!gemm256_applicable(G)) {
-        set_last_error("gemm256: M,N must be multiples of 256 and K of 64");
+        set_last_error("gemm_f16: M,N must be multiples of 256 and K of 64");
         return ANCE_E_INVALID;
     }
-    return glds ? launch256<true>(epi, G, st) : launch256<false>(epi, G, st);
+    return G.debug_mode ? launch256<true>(epi, G, st) : launch256<false>(epi, G, st);
 }
 
 }  // namespace ance
+
+// Test / measurement hook (include/ance_amd.h): the encoder's GEMM kernel on caller-provided data.
+extern "C" int ance_debug_gemm(int ablate, int epi, const void *d_a_f16, const void *d_b_f16, int M, int N, int K,
+                               const float *d_bias, void *d_out, const float *d_res32, void *stream) {
+    using namespace ance;
+    if (!d_a_f16 || !d_b_f16 || !d_bias || !d_out || epi < 0 || epi > 2 || (epi == EPI_RES32 && !d_res32)) {
+        set_last_error("ance_debug_gemm: invalid argument");
+        return ANCE_E_INVALID;
+    }
+    GemmArgs G;
+    memset(&G, 0, sizeof(G));
+    G.A = (const _Float16 *)d_a_f16; G.lda = K; G.B = (const _Float16 *)d_b_f16; G.ldb = K;
+    G.M = M; G.N = N; G.K = K; G.bias = d_bias; G.ldc = N; G.scale = 1.0f; G.scale_cols = 0;
+    G.debug_mode = ablate;
+    if (epi == EPI_RES32) { G.out32 = (float *)d_out; G.res32 = d_res32; }
+    else G.out16 = (_Float16 *)d_out;
+    ProfScope ps(PC_GEMM_FFN1, (hipStream_t)stream, 2.0 * M * (double)N * K);
+    int rc = launch_gemm_f16(epi, G, (hipStream_t)stream);
+    return rc ? rc : check_launch("ance_debug_gemm");
+}

@@ -1,4 +1,4 @@
-// Internal interface of the encoder's fp16 MFMA GEMM (see gemm_f16.hip).
+// Internal interface of the encoder's fp16 MFMA GEMM (see gemm256_f16.hip).
 #pragma once
 #include "common.h"
 
@@ -10,7 +10,7 @@ struct GemmArgs {
     const _Float16 *A;  // [M, K], row stride lda (halves)
     const _Float16 *B;  // [N, K], row stride ldb
     int lda, ldb;
-    int M, N, K;        // M, N multiples of 128; K multiple of 64
+    int M, N, K;        // M, N multiples of 256; K multiple of 64
     const float *bias;  // per column n (EPI_QK / GELU / RES32) or per row m (EPI_VT)
     _Float16 *out16;
     float *out32;
@@ -20,13 +20,11 @@ struct GemmArgs {
     int scale_cols;
     const int *col_map;  // EPI_VT: token n -> destination column
     int n_valid;         // EPI_VT: columns n >= n_valid are not stored
+    int debug_mode;      // ance_debug_gemm ablations: 1 = no loads after tile 0, 2 = no MFMA, 4 = all blocks load tile (0,0)
 };
 
-// Dispatcher: 256 x 256 tile kernel (gemm256_f16.hip) when the shape allows, else the 128 x 128 one.
-// ANCE_GEMM=128|256reg|256glds overrides the choice (A/B measurements).
+// 256 x 256 x 64 tile kernel of gemm256_f16.hip (M, N multiples of 256, K of 64).
 int launch_gemm_f16(int epi, const GemmArgs &args, hipStream_t stream);
-int launch_gemm128_f16(int epi, const GemmArgs &args, hipStream_t stream);
 bool gemm256_applicable(const GemmArgs &args);
-int launch_gemm256_f16(int epi, const GemmArgs &args, bool glds, hipStream_t stream);
 
 }  // namespace ance

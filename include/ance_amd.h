@@ -158,6 +158,16 @@ int ance_encode_records(AnceEncoder *enc, const void *d_records, const int32_t *
 int ance_encode_ids(AnceEncoder *enc, const int32_t *d_ids, int64_t ld_ids, const int32_t *d_lens,
                     const int32_t *h_lens, int64_t n, int L, int n_chunks, float *d_out, void *stream);
 
+/*
+ * Test / measurement hook: C = A . B^T (+ epilogue) with the encoder's GEMM kernel on caller data.
+ *   epi 0: out f16 = acc + bias[n]; 1: out f16 = gelu(acc + bias[n]); 2: out f32 = acc + bias[n] + res32
+ *   d_a_f16 [M,K], d_b_f16 [N,K] fp16 row-major; M, N multiples of 256, K of 64.
+ *   ablate 0: the product kernel.  Bits select a measurement ablation (results are then WRONG on
+ *   purpose): 1 = no global loads after the first K-tile, 2 = no MFMA, 4 = every block loads tile (0,0).
+ */
+int ance_debug_gemm(int ablate, int epi, const void *d_a_f16, const void *d_b_f16, int M, int N, int K,
+                    const float *d_bias, void *d_out, const float *d_res32, void *stream);
+
 /* Introspection for tests / bench: algorithmic FLOPs of the last ance_encode_* call cannot be
  * known without a sync, so the library exposes the pure function instead:
  * F_enc(T) = 169,869,312 T + 36,864 T^2 + 1,179,648 per sequence of T tokens. */

@@ -3,6 +3,7 @@
 //
 //   abi_probe search  <n_rows> <n_queries> <k> <reps>
 //   abi_probe encode  <n_passages> <seq_len> <layers> <reps> [max_tokens]
+//   abi_probe gemm    <ablate> <epi> <M> <N> <K> <reps>
 //
 // Build: hipcc -O2 -std=c++17 tools/abi_probe.cpp -Iinclude -Lance_amd -lance_amd -Wl,-rpath,'$ORIGIN/../ance_amd' -o tools/abi_probe
 #include <hip/hip_runtime.h>
@@ -167,10 +168,48 @@ static int run_encode(int64_t n, int L, int layers, int reps, int max_tokens) {
     return 0;
 }
 
+static int run_gemm(int variant, int epi, int M, int N, int K, int reps) {
+    std::mt19937_64 g(3);
+    std::normal_distribution<float> nd(0.f, 1.f);
+    std::vector<_Float16> a((size_t)M * K), b((size_t)N * K);
+    // fill a 1M-element random block and tile it (host RNG is slow)
+    std::vector<_Float16> blk(1 << 20);
+    for (auto &v : blk) v = (_Float16)(nd(g) * 0.5f);
+    for (size_t i = 0; i < a.size(); ++i) a[i] = blk[(i * 2654435761ull) & ((1 << 20) - 1)];
+    for (size_t i = 0; i < b.size(); ++i) b[i] = blk[(i * 40503ull + 17) & ((1 << 20) - 1)];
+    _Float16 *da, *db;
+    float *dbias, *dres = nullptr;
+    void *dout;
+    CK(hipMalloc(&da, a.size() * 2)); CK(hipMemcpy(da, a.data(), a.size() * 2, hipMemcpyHostToDevice));
+    CK(hipMalloc(&db, b.size() * 2)); CK(hipMemcpy(db, b.data(), b.size() * 2, hipMemcpyHostToDevice));
+    CK(hipMalloc(&dbias, (size_t)N * 4)); CK(hipMemset(dbias, 0, (size_t)N * 4));
+    CK(hipMalloc(&dout, (size_t)M * N * 4));
+    if (epi == 2) { CK(hipMalloc(&dres, (size_t)M * N * 4)); CK(hipMemset(dres, 0, (size_t)M * N * 4)); }
+    hipStream_t st;
+    CK(hipStreamCreate(&st));
+    AK(ance_debug_gemm(variant, epi, da, db, M, N, K, dbias, dout, dres, st));
+    CK(hipStreamSynchronize(st));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    CK(hipEventRecord(e0, st));
+    for (int r = 0; r < reps; ++r) AK(ance_debug_gemm(variant, epi, da, db, M, N, K, dbias, dout, dres, st));
+    CK(hipEventRecord(e1, st));
+    CK(hipEventSynchronize(e1));
+    float ms = 0;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    const double us = 1e3 * ms / reps;
+    printf("{\"probe\":\"gemm\",\"ablate\":%d,\"epi\":%d,\"M\":%d,\"N\":%d,\"K\":%d,\"us\":%.1f,\"tflops\":%.1f}\n", variant, epi, M,
+           N, K, us, 2.0 * M * N * K / us / 1e6);
+    hipFree(da); hipFree(db); hipFree(dbias); hipFree(dout); if (dres) hipFree(dres);
+    return 0;
+}
+
 int main(int argc, char **argv) {
+    if (argc >= 8 && !strcmp(argv[1], "gemm"))
+        return run_gemm(atoi(argv[2]), atoi(argv[3]), atoi(argv[4]), atoi(argv[5]), atoi(argv[6]), atoi(argv[7]));
     if (argc >= 6 && !strcmp(argv[1], "search")) return run_search(atoll(argv[2]), atoll(argv[3]), atoi(argv[4]), atoi(argv[5]));
     if (argc >= 6 && !strcmp(argv[1], "encode"))
         return run_encode(atoll(argv[2]), atoi(argv[3]), atoi(argv[4]), atoi(argv[5]), argc > 6 ? atoi(argv[6]) : 65536);
-    fprintf(stderr, "usage: abi_probe search n nq k reps | abi_probe encode n L layers reps [max_tokens]\n");
+    fprintf(stderr, "usage: abi_probe search n nq k reps | encode n L layers reps [max_tokens] | gemm ablate epi M N K reps\n");
     return 1;
 }
