@@ -326,11 +326,19 @@ struct AnceEncoder {
     float *word, *pos, *type0, *eln_w, *eln_b;
     std::vector<LayerW> layers;
     float *head_w, *head_b, *norm_w, *norm_b;
-    // workspace
+    // workspace: two independent "lanes" (activation sets) so that consecutive micro-batches can run
+    // on two streams -- the MFMA-bound GEMMs of one overlap the HBM-bound LayerNorm / attention /
+    // epilogue phases of the other
     int tcap, vcap, scap;
-    int *seq_off, *seq_vtcol, *seq_len, *tok_id, *tok_pos, *tok_vtcol, *lens_fetch;
-    float *h32, *pre32;
-    _Float16 *h16, *qk16, *vt16, *ctx16, *ffn16;
+    int *lens_fetch;
+    struct Lane {
+        int *seq_off, *seq_vtcol, *seq_len, *tok_id, *tok_pos, *tok_vtcol;
+        float *h32, *pre32;
+        _Float16 *h16, *qk16, *vt16, *ctx16, *ffn16;
+    } lane[2];
+    int n_lanes;
+    hipStream_t side[2];
+    hipEvent_t ev_fork, ev_join[2];
     std::vector<int32_t> host_lens;
     bool cls_tail;  // run the last layer's post-attention part on the [CLS] rows only (ANCE_CLS_TAIL=0 disables)
 };
@@ -383,20 +391,21 @@ void layout_workspace(const AnceEncoderDesc *d, Arena &a, AnceEncoder *e) {
     const int tcap = d->max_tokens;
     const int scap = tcap < S_CAP_MAX ? tcap : S_CAP_MAX;
     const int vcap = (int)align_up((size_t)tcap + tcap / 4 + 256, 256);
-    int *seq_off = a.take<int>(scap + 1), *seq_vtcol = a.take<int>(scap), *seq_len = a.take<int>(scap);
-    int *tok_id = a.take<int>(tcap), *tok_pos = a.take<int>(tcap), *tok_vtcol = a.take<int>(tcap);
     int *lens_fetch = a.take<int>(FETCH_CHUNK);
-    float *h32 = a.take<float>((size_t)tcap * H), *pre32 = a.take<float>((size_t)tcap * H);
-    _Float16 *h16 = a.take<_Float16>((size_t)tcap * H);
-    _Float16 *qk16 = a.take<_Float16>((size_t)tcap * 2 * H);
-    _Float16 *vt16 = a.take<_Float16>((size_t)H * vcap);
-    _Float16 *ctx16 = a.take<_Float16>((size_t)tcap * H);
-    _Float16 *ffn16 = a.take<_Float16>((size_t)tcap * d->intermediate);
     if (e) {
-        e->tcap = tcap; e->scap = scap; e->vcap = vcap;
-        e->seq_off = seq_off; e->seq_vtcol = seq_vtcol; e->seq_len = seq_len;
-        e->tok_id = tok_id; e->tok_pos = tok_pos; e->tok_vtcol = tok_vtcol; e->lens_fetch = lens_fetch;
-        e->h32 = h32; e->pre32 = pre32; e->h16 = h16; e->qk16 = qk16; e->vt16 = vt16; e->ctx16 = ctx16; e->ffn16 = ffn16;
+        e->tcap = tcap; e->scap = scap; e->vcap = vcap; e->lens_fetch = lens_fetch;
+    }
+    for (int ln = 0; ln < 2; ++ln) {
+        AnceEncoder::Lane L;
+        L.seq_off = a.take<int>(scap + 1); L.seq_vtcol = a.take<int>(scap); L.seq_len = a.take<int>(scap);
+        L.tok_id = a.take<int>(tcap); L.tok_pos = a.take<int>(tcap); L.tok_vtcol = a.take<int>(tcap);
+        L.h32 = a.take<float>((size_t)tcap * H); L.pre32 = a.take<float>((size_t)tcap * H);
+        L.h16 = a.take<_Float16>((size_t)tcap * H);
+        L.qk16 = a.take<_Float16>((size_t)tcap * 2 * H);
+        L.vt16 = a.take<_Float16>((size_t)H * vcap);
+        L.ctx16 = a.take<_Float16>((size_t)tcap * H);
+        L.ffn16 = a.take<_Float16>((size_t)tcap * d->intermediate);
+        if (e) e->lane[ln] = L;
     }
 }
 
@@ -410,7 +419,8 @@ void cpy32(const void *src, float *dst, size_t n, hipStream_t st) {
 }
 
 int encode_impl(AnceEncoder *e, const int32_t *base, int64_t ld, const int32_t *d_lens, const int32_t *h_lens, int hdr,
-                int64_t n, int L, int n_chunks, float *d_out, hipStream_t st) {
+                int64_t n, int L, int n_chunks, float *d_out, hipStream_t caller_st) {
+    hipStream_t st = caller_st;
     if (!e || !base || !d_out || n < 0 || L < 1 || n_chunks < 1 || L % n_chunks) {
         set_last_error("ance_encode: invalid argument");
         return ANCE_E_INVALID;
@@ -422,6 +432,8 @@ int encode_impl(AnceEncoder *e, const int32_t *base, int64_t ld, const int32_t *
     }
     const AnceEncoderDesc &D = e->d;
     const int I = D.intermediate;
+    int mb_index = 0;
+    bool forked = false;
 
     for (int64_t r0 = 0; r0 < n; r0 += FETCH_CHUNK) {
         const int nr = (int)((n - r0) < FETCH_CHUNK ? (n - r0) : FETCH_CHUNK);
@@ -438,10 +450,18 @@ int encode_impl(AnceEncoder *e, const int32_t *base, int64_t ld, const int32_t *
                 return check_launch("ance_encode: length read-back");
             hl = e->host_lens.data();
         }
+        if (e->n_lanes > 1 && !forked) {  // side streams start after everything already queued by the caller
+            (void)hipEventRecord(e->ev_fork, caller_st);
+            for (int ln = 0; ln < e->n_lanes; ++ln) (void)hipStreamWaitEvent(e->side[ln], e->ev_fork, 0);
+            forked = true;
+        }
         // ---- greedy micro-batches over the sequences (record, chunk) of this block of records ---
         const int64_t gs_end = (int64_t)nr * n_chunks;
         int64_t gs = 0;
         while (gs < gs_end) {
+            const AnceEncoder::Lane &LN = e->lane[mb_index % e->n_lanes];
+            hipStream_t st = e->n_lanes > 1 ? e->side[mb_index % e->n_lanes] : caller_st;
+            ++mb_index;
             int S = 0, T = 0, V = 0, maxlen = 1;
             int64_t g = gs;
             while (g < gs_end && S < e->scap) {
@@ -468,8 +488,8 @@ int encode_impl(AnceEncoder *e, const int32_t *base, int64_t ld, const int32_t *
             P.base = base; P.ld = ld; P.lens = d_lens; P.hdr = hdr;
             P.g0 = r0 * n_chunks + gs; P.S = S; P.L = L; P.n_chunks = n_chunks; P.Lc = Lc;
             P.pad_id = D.pad_token_id; P.arch = D.arch; P.T = T; P.Tpad = Tpad;
-            P.seq_off = e->seq_off; P.seq_vtcol = e->seq_vtcol; P.seq_len = e->seq_len;
-            P.tok_id = e->tok_id; P.tok_pos = e->tok_pos; P.tok_vtcol = e->tok_vtcol;
+            P.seq_off = LN.seq_off; P.seq_vtcol = LN.seq_vtcol; P.seq_len = LN.seq_len;
+            P.tok_id = LN.tok_id; P.tok_pos = LN.tok_pos; P.tok_vtcol = LN.tok_vtcol;
             {
                 ProfScope ps(PC_PLAN, st);
                 hipLaunchKernelGGL(plan_kernel, dim3(1), dim3(1024), 0, st, P);
@@ -478,8 +498,8 @@ int encode_impl(AnceEncoder *e, const int32_t *base, int64_t ld, const int32_t *
             }
             {
             ProfScope pe(PC_EMBED, st);
-            hipLaunchKernelGGL(embed_ln_kernel, dim3(Tpad / 4), dim3(256), 0, st, e->tok_id, e->tok_pos, Tpad, e->word, e->pos,
-                               e->type0, D.vocab_size, D.max_position, e->eln_w, e->eln_b, D.ln_eps, e->h32, e->h16);
+            hipLaunchKernelGGL(embed_ln_kernel, dim3(Tpad / 4), dim3(256), 0, st, LN.tok_id, LN.tok_pos, Tpad, e->word, e->pos,
+                               e->type0, D.vocab_size, D.max_position, e->eln_w, e->eln_b, D.ln_eps, LN.h32, LN.h16);
             }
             // Only the [CLS] row of the last layer reaches the head (model/models.py:49,152): after the
             // last layer's K / V projections everything runs on the S compact [CLS] rows.
@@ -493,8 +513,8 @@ int encode_impl(AnceEncoder *e, const int32_t *base, int64_t ld, const int32_t *
                 GemmArgs G;
                 memset(&G, 0, sizeof(G));
                 // Q | K projection
-                G.A = e->h16; G.lda = H; G.B = W.wqk; G.ldb = H; G.M = Tpad; G.N = 2 * H; G.K = H;
-                G.bias = W.bqk; G.out16 = e->qk16; G.ldc = 2 * H; G.scale = 0.125f; G.scale_cols = H;
+                G.A = LN.h16; G.lda = H; G.B = W.wqk; G.ldb = H; G.M = Tpad; G.N = 2 * H; G.K = H;
+                G.bias = W.bqk; G.out16 = LN.qk16; G.ldc = 2 * H; G.scale = 0.125f; G.scale_cols = H;
                 int rc;
                 {
                     ProfScope ps(PC_GEMM_QK, st, 2.0 * T * (2.0 * H) * H);
@@ -503,15 +523,15 @@ int encode_impl(AnceEncoder *e, const int32_t *base, int64_t ld, const int32_t *
                 if (rc) return rc;
                 // V^T = Wv h^T
                 memset(&G, 0, sizeof(G));
-                G.A = W.wv; G.lda = H; G.B = e->h16; G.ldb = H; G.M = H; G.N = Tpad; G.K = H;
-                G.bias = W.bv; G.out16 = e->vt16; G.ldc = ldvt; G.col_map = e->tok_vtcol; G.n_valid = T;
+                G.A = W.wv; G.lda = H; G.B = LN.h16; G.ldb = H; G.M = H; G.N = Tpad; G.K = H;
+                G.bias = W.bv; G.out16 = LN.vt16; G.ldc = ldvt; G.col_map = LN.tok_vtcol; G.n_valid = T;
                 {
                     ProfScope ps(PC_GEMM_VT, st, 2.0 * T * (double)H * H);
                     rc = launch_gemm_f16(EPI_VT, G, st);
                 }
                 if (rc) return rc;
                 AttnArgs A;
-                A.qk = e->qk16; A.vt = e->vt16; A.ctx = e->ctx16; A.seq_off = e->seq_off; A.seq_vtcol = e->seq_vtcol;
+                A.qk = LN.qk16; A.vt = LN.vt16; A.ctx = LN.ctx16; A.seq_off = LN.seq_off; A.seq_vtcol = LN.seq_vtcol;
                 A.ld_qk = 2 * H; A.ld_vt = ldvt; A.ld_ctx = H; A.n_heads = D.n_heads; A.cls_only = tail ? 1 : 0;
                 {
                     ProfScope ps(PC_ATTN, st, 0.0);
@@ -519,16 +539,16 @@ int encode_impl(AnceEncoder *e, const int32_t *base, int64_t ld, const int32_t *
                 }
                 if (rc) return rc;
                 // attention.output.dense + residual
-                const float *resid = e->h32;
+                const float *resid = LN.h32;
                 if (tail) {  // compact residual rows, parked in the (currently dead) FFN buffer
-                    float *rc = reinterpret_cast<float *>(e->ffn16);
+                    float *rc = reinterpret_cast<float *>(LN.ffn16);
                     ProfScope ps(PC_LN, st);
-                    hipLaunchKernelGGL(gather_cls_kernel, dim3(S_pad / 4), dim3(256), 0, st, e->h32, e->seq_off, S, S_pad, rc);
+                    hipLaunchKernelGGL(gather_cls_kernel, dim3(S_pad / 4), dim3(256), 0, st, LN.h32, LN.seq_off, S, S_pad, rc);
                     resid = rc;
                 }
                 memset(&G, 0, sizeof(G));
-                G.A = e->ctx16; G.lda = H; G.B = W.wo; G.ldb = H; G.M = Mrows; G.N = H; G.K = H;
-                G.bias = W.bo; G.out32 = e->pre32; G.res32 = resid; G.ldc = H;
+                G.A = LN.ctx16; G.lda = H; G.B = W.wo; G.ldb = H; G.M = Mrows; G.N = H; G.K = H;
+                G.bias = W.bo; G.out32 = LN.pre32; G.res32 = resid; G.ldc = H;
                 {
                     ProfScope ps(PC_GEMM_OUT, st, 2.0 * Mwork * (double)H * H);
                     rc = launch_gemm_f16(EPI_RES32, G, st);
@@ -536,13 +556,13 @@ int encode_impl(AnceEncoder *e, const int32_t *base, int64_t ld, const int32_t *
                 if (rc) return rc;
                 {
                     ProfScope ps(PC_LN, st);
-                    hipLaunchKernelGGL(ln_kernel, dim3(Mrows / 4), dim3(256), 0, st, e->pre32, Mrows, W.ln1w, W.ln1b, D.ln_eps,
-                                       e->h32, e->h16);
+                    hipLaunchKernelGGL(ln_kernel, dim3(Mrows / 4), dim3(256), 0, st, LN.pre32, Mrows, W.ln1w, W.ln1b, D.ln_eps,
+                                       LN.h32, LN.h16);
                 }
                 // intermediate.dense + GELU
                 memset(&G, 0, sizeof(G));
-                G.A = e->h16; G.lda = H; G.B = W.w1; G.ldb = H; G.M = Mrows; G.N = I; G.K = H;
-                G.bias = W.b1; G.out16 = e->ffn16; G.ldc = I;
+                G.A = LN.h16; G.lda = H; G.B = W.w1; G.ldb = H; G.M = Mrows; G.N = I; G.K = H;
+                G.bias = W.b1; G.out16 = LN.ffn16; G.ldc = I;
                 {
                     ProfScope ps(PC_GEMM_FFN1, st, 2.0 * Mwork * (double)I * H);
                     rc = launch_gemm_f16(EPI_GELU, G, st);
@@ -550,8 +570,8 @@ int encode_impl(AnceEncoder *e, const int32_t *base, int64_t ld, const int32_t *
                 if (rc) return rc;
                 // output.dense + residual
                 memset(&G, 0, sizeof(G));
-                G.A = e->ffn16; G.lda = I; G.B = W.w2; G.ldb = I; G.M = Mrows; G.N = H; G.K = I;
-                G.bias = W.b2; G.out32 = e->pre32; G.res32 = e->h32; G.ldc = H;
+                G.A = LN.ffn16; G.lda = I; G.B = W.w2; G.ldb = I; G.M = Mrows; G.N = H; G.K = I;
+                G.bias = W.b2; G.out32 = LN.pre32; G.res32 = LN.h32; G.ldc = H;
                 {
                     ProfScope ps(PC_GEMM_FFN2, st, 2.0 * Mwork * (double)I * H);
                     rc = launch_gemm_f16(EPI_RES32, G, st);
@@ -559,16 +579,30 @@ int encode_impl(AnceEncoder *e, const int32_t *base, int64_t ld, const int32_t *
                 if (rc) return rc;
                 {
                     ProfScope ps(PC_LN, st);
-                    hipLaunchKernelGGL(ln_kernel, dim3(Mrows / 4), dim3(256), 0, st, e->pre32, Mrows, W.ln2w, W.ln2b, D.ln_eps,
-                                       e->h32, e->h16);
+                    hipLaunchKernelGGL(ln_kernel, dim3(Mrows / 4), dim3(256), 0, st, LN.pre32, Mrows, W.ln2w, W.ln2b, D.ln_eps,
+                                       LN.h32, LN.h16);
                 }
             }
             {
                 ProfScope ps(PC_HEAD, st);
-                hipLaunchKernelGGL(head_kernel, dim3(S), dim3(256), 0, st, e->h32, e->seq_off, cls_tail ? 1 : 0, e->head_w, e->head_b,
+                hipLaunchKernelGGL(head_kernel, dim3(S), dim3(256), 0, st, LN.h32, LN.seq_off, cls_tail ? 1 : 0, e->head_w, e->head_b,
                                    e->norm_w, e->norm_b, D.has_head, d_out + (size_t)(r0 * n_chunks + gs) * HEAD_OUT);
             }
             gs = g;
+        }
+        if (forked && r0 + FETCH_CHUNK < n && !h_lens) {
+            // the next block of records needs a length read-back on the caller's stream: join first
+            for (int ln = 0; ln < e->n_lanes; ++ln) {
+                (void)hipEventRecord(e->ev_join[ln], e->side[ln]);
+                (void)hipStreamWaitEvent(caller_st, e->ev_join[ln], 0);
+            }
+            forked = false;
+        }
+    }
+    if (forked) {  // the caller's stream continues only after both side streams are done
+        for (int ln = 0; ln < e->n_lanes; ++ln) {
+            (void)hipEventRecord(e->ev_join[ln], e->side[ln]);
+            (void)hipStreamWaitEvent(caller_st, e->ev_join[ln], 0);
         }
     }
     return check_launch("ance_encode");
@@ -613,6 +647,23 @@ extern "C" int ance_encoder_create(const AnceEncoderDesc *desc, const void *cons
     {
         const char *ct = getenv("ANCE_CLS_TAIL");
         e->cls_tail = !(ct && ct[0] == '0');
+        const char *ns = getenv("ANCE_ENCODER_STREAMS");
+        e->n_lanes = (ns && ns[0] == '1') ? 1 : 2;
+    }
+    for (int ln = 0; ln < 2; ++ln) {
+        e->side[ln] = nullptr;
+        e->ev_join[ln] = nullptr;
+    }
+    e->ev_fork = nullptr;
+    if (e->n_lanes > 1) {
+        bool ok = hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) == hipSuccess;
+        for (int ln = 0; ln < 2 && ok; ++ln)
+            ok = hipStreamCreateWithFlags(&e->side[ln], hipStreamNonBlocking) == hipSuccess &&
+                 hipEventCreateWithFlags(&e->ev_join[ln], hipEventDisableTiming) == hipSuccess;
+        if (!ok) {
+            delete e;
+            return check_launch("ance_encoder_create: streams");
+        }
     }
     Arena wa, xa;
     wa.base = reinterpret_cast<char *>(align_up((uintptr_t)d_weight_arena, 256));
@@ -664,7 +715,18 @@ extern "C" int ance_encoder_create(const AnceEncoderDesc *desc, const void *cons
     return ANCE_OK;
 }
 
-extern "C" void ance_encoder_destroy(AnceEncoder *enc) { delete enc; }
+extern "C" void ance_encoder_destroy(AnceEncoder *enc) {
+    if (!enc) return;
+    for (int ln = 0; ln < 2; ++ln) {
+        if (enc->side[ln]) {
+            (void)hipStreamSynchronize(enc->side[ln]);
+            (void)hipStreamDestroy(enc->side[ln]);
+        }
+        if (enc->ev_join[ln]) (void)hipEventDestroy(enc->ev_join[ln]);
+    }
+    if (enc->ev_fork) (void)hipEventDestroy(enc->ev_fork);
+    delete enc;
+}
 
 extern "C" int ance_encode_records(AnceEncoder *enc, const void *d_records, const int32_t *h_lens, int64_t n, int L,
                                    int n_chunks, float *d_out, void *stream) {

@@ -105,6 +105,18 @@ def random_init_roberta_base(torch, n_layers, seed=0):
     return sd
 
 
+def pmc_traffic(leg, kernel):
+    """HBM bytes per launch of the dominant kernel from rocprofv3 PMC passes (FETCH_SIZE x2 for wide
+    reads on gfx950 + WRITE_SIZE, MI355X_MICROARCH.md HBM section).  PMC cannot be collected from
+    inside this process; the numbers are read from profiles/pmc_traffic.json, which
+    scripts/gpu_pmc.sh regenerates on the same workload (null if the file has no entry)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            return json.load(f).get(leg, {}).get(kernel)
+    except Exception:
+        return None
+
+
 def timed_steps(fn, steps, warmup, dist_on, torch):
     for _ in range(warmup):
         fn()
@@ -220,7 +232,7 @@ def main():
             sd = random_init_roberta_base(torch, a.layers, seed=0)
             enc = Encoder(sd, ARCH_ROBERTA, "roberta.", True, max_seq_len=min(a.seq_len, 512),
                           max_tokens=a.max_tokens, device=dev)
-            del sd
+            sd_for_probe = sd
             rng = np.random.default_rng(1234 + rank)
             rec, lens = synthetic_records(rng, a.encode_block, a.seq_len)
             rec_d = torch.from_numpy(rec).to(dev)
@@ -234,10 +246,26 @@ def main():
             for _ in range(max(a.warmup, 1)):
                 step_enc()
             torch.cuda.synchronize()
-            _lib.profile_enable(True)
             dt = timed_steps(step_enc, a.steps, 0, dist_on, torch)
+            # Roofline pass.  The product overlaps consecutive micro-batches on two internal streams, so
+            # inside the timed region kernels of two micro-batches share the chip and a per-kernel
+            # duration is not a property of that kernel.  The same K steps are therefore repeated on a
+            # single-stream handle with the library's HIP events on (launch stream), kernels isolated.
+            os.environ["ANCE_ENCODER_STREAMS"] = "1"
+            enc1 = Encoder(sd_for_probe, ARCH_ROBERTA, "roberta.", True, max_seq_len=min(a.seq_len, 512),
+                           max_tokens=a.max_tokens, device=dev)
+            os.environ.pop("ANCE_ENCODER_STREAMS", None)
+            enc1.encode_records(rec_d, h_lens=lens, out=emb)
+            torch.cuda.synchronize()
+            _lib.profile_enable(True)
+            t1 = time.perf_counter()
+            for _ in range(a.steps):
+                enc1.encode_records(rec_d, h_lens=lens, out=emb)
+            torch.cuda.synchronize()
+            dt_iso = time.perf_counter() - t1
             prof = _lib.profile_read()
             _lib.profile_enable(False)
+            del enc1
             pps = world * a.encode_block * a.steps / dt
             out["value"] = pps
             out["ms_per_step"] = 1e3 * dt / a.steps
@@ -249,8 +277,10 @@ def main():
             ach = prof[dom]["work"] / (prof[dom]["ms"] * 1e-3) / 1e12 if prof[dom]["ms"] > 0 else None
             all_gemm_ms = sum(prof[c]["ms"] for c in gemm_cats)
             all_gemm_work = sum(prof[c]["work"] for c in gemm_cats)
-            out["roofline"] = {"bound": "mfma", "kernel": "gemm_f16_kernel (%s)" % dom, "achieved": ach, "peak": PEAK_F16_TF,
-                               "unit": "TFLOP/s", "frac": (ach / PEAK_F16_TF) if ach else None, "traffic": None,
+            out["roofline"] = {"bound": "mfma", "kernel": "gemm256_f16_kernel (%s)" % dom, "achieved": ach, "peak": PEAK_F16_TF,
+                               "unit": "TFLOP/s", "frac": (ach / PEAK_F16_TF) if ach else None, "traffic": pmc_traffic("encode", dom),
+                               "timing": "HIP events on the launch stream, single-stream pass of the same %d steps "
+                                         "(%.1f ms/step isolated vs %.1f ms/step overlapped)" % (a.steps, 1e3 * dt_iso / a.steps, 1e3 * dt / a.steps),
                                "all_gemm_tflops": all_gemm_work / (all_gemm_ms * 1e-3) / 1e12 if all_gemm_ms > 0 else None,
                                "by_kernel": by_kernel}
             out["encode"] = {"passages_per_sec": pps, "tokens_per_sec": pps * float(lens.mean()),
@@ -260,7 +290,7 @@ def main():
                              "end_to_end_mfma_frac": world * flops_alg * a.steps / dt / 1e12 / (PEAK_F16_TF * world),
                              "hbm_min_bytes_per_passage": 4 + 4 * a.seq_len + 3072,
                              "full_corpus_seconds_est": N_PASSAGES / pps}
-            del enc, rec_d, emb
+            del enc, rec_d, emb, sd_for_probe
             torch.cuda.empty_cache()
         except Exception as e:  # keep going: a bench line with the other leg is still informative
             import traceback
@@ -303,7 +333,7 @@ def main():
                              "full_train_queries_seconds_est": N_TRAIN_QUERIES / qps,
                              "roofline": {"bound": "mfma", "kernel": "ip_topk_scan_kernel (fp32 MFMA 32x32x2)",
                                           "achieved": ach, "peak": PEAK_F32_TF, "unit": "TFLOP/s",
-                                          "frac": (ach / PEAK_F32_TF) if ach else None, "traffic": None,
+                                          "frac": (ach / PEAK_F32_TF) if ach else None, "traffic": pmc_traffic("search", "ip_topk_scan"),
                                           "ms_per_launch": scan["ms"] / scan["count"] if scan["count"] else None,
                                           "finalize_ms_per_launch": prof["topk_finalize"]["ms"] / max(prof["topk_finalize"]["count"], 1),
                                           "hbm_read_gbs_min": ((n_loc * 768 * 4.0) / (scan["ms"] / max(scan["count"], 1) * 1e-3) / 1e9)

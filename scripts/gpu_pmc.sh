@@ -5,8 +5,8 @@ cd "$(dirname "$0")/.."
 mkdir -p gpurun_out/pmc
 export TMPDIR=/tmp
 export LD_LIBRARY_PATH=/opt/rocm/lib:${LD_LIBRARY_PATH:-}
-S="tools/abi_probe search ${PMC_N:-2000000} ${PMC_NQ:-4096} 200 2"
-E="tools/abi_probe encode ${PMC_NP:-4096} 128 12 2 65536"
+S="tools/abi_probe search ${PMC_N:-8841823} ${PMC_NQ:-4096} 200 2"
+E="tools/abi_probe encode ${PMC_NP:-16384} 128 12 2 65536"
 echo "== plain runs"; timeout 300 $S; timeout 300 $E
 for what in search encode; do
   cmd="$S"; [ $what = encode ] && cmd="$E"
@@ -19,4 +19,4 @@ for what in search encode; do
   done
 done
 find gpurun_out/pmc -name "*.csv" | head -30
-python scripts/summarize_pmc.py gpurun_out/pmc 2>&1 | head -60
+python scripts/summarize_pmc.py gpurun_out/pmc gpurun_out/pmc/pmc_traffic.json 2>&1 | head -70
