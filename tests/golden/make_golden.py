@@ -148,9 +148,46 @@ def golden_end_to_end():
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+def golden_dpr():
+    """validate / GenerateNegativePassaageID / has_answer of the reference's DPR driver on synthetic
+    passages and answers (unicode, punctuation, multi-token and empty-token answers)."""
+    import importlib
+    ref_harness.load_reference()
+    D = importlib.import_module("run_ann_data_gen_dpr")
+    rng = np.random.default_rng(31)
+    vocab = ["the", "Paris", "paris", "New", "York", "new", "york", "café", "CAFÉ", "naïve", "1969", "Apollo", "11",
+             "moon", "U.S.", "u.s.", "state-of-the-art", "O'Neil", "rock", "&", "roll", "Zürich", "3.14", "pi", "ﬁ",
+             "Ａ", "İstanbul", "istanbul", "élan", "e\u0301lan", ",", ".", "(", ")", "dog", "cat", "blue", "red"]
+    n_p = 400
+    passages = {}
+    for pid in range(n_p):
+        words = [vocab[int(j)] for j in rng.integers(0, len(vocab), size=int(rng.integers(5, 40)))]
+        passages[pid] = (" ".join(words), "title %d" % pid)
+    answers_pool = [["Paris"], ["new york"], ["New  York"], ["café"], ["Apollo 11"], ["u.s."], ["rock & roll"],
+                    ["state-of-the-art"], ["3.14"], ["Zürich", "zurich"], ["istanbul"], ["elan"], ["moon", "dog"],
+                    ["blue cat"], ["."], [""], ["O'Neil"], ["red dog cat"], ["ﬁ"], ["A"], ["naive"]]
+    nq, k = 50, 30
+    answers = [answers_pool[int(j)] for j in rng.integers(0, len(answers_pool), size=nq)]
+    p2id = np.arange(n_p, dtype=np.int64)
+    q2id = np.arange(nq, dtype=np.int64)
+    I = np.stack([rng.choice(n_p, size=k, replace=False) for _ in range(nq)]).astype(np.int64)
+    pos = [int(I[i, rng.integers(0, 6)]) for i in range(nq)]
+    hits = D.validate(passages, answers, I, q2id, p2id)
+    args = types.SimpleNamespace(negative_sample=9)
+    neg = D.GenerateNegativePassaageID(args, passages, answers, q2id, p2id, I, pos)
+    from utils.dpr_utils import SimpleTokenizer, has_answer
+    tok = SimpleTokenizer()
+    single = [[bool(has_answer(a, passages[pid][0], tok)) for pid in range(40)] for a in answers_pool]
+    with open(os.path.join(OUT, "dpr_postsearch.json"), "w") as f:
+        json.dump(dict(passages={str(k_): v for k_, v in passages.items()}, answers=answers, answers_pool=answers_pool,
+                       I=I.tolist(), pos=pos, negative_sample=9, hits=hits,
+                       neg={str(k_): [int(x) for x in v] for k_, v in neg.items()}, single=single), f)
+    return dict(top20=hits[19], n_neg=sum(len(v) for v in neg.values()))
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    info = dict(encoder=golden_encoder(), postsearch=golden_postsearch(), e2e=golden_end_to_end(),
+    info = dict(encoder=golden_encoder(), postsearch=golden_postsearch(), e2e=golden_end_to_end(), dpr=golden_dpr(),
                 torch=torch.__version__, numpy=np.__version__)
     with open(os.path.join(OUT, "manifest.json"), "w") as f:
         json.dump(info, f, indent=1)

@@ -1,0 +1,82 @@
+"""DPR host logic (ance_amd.dpr: answer matching, top-k hit accuracy, answer-filtered negatives) against
+golden vectors produced by the reference's own run_ann_data_gen_dpr.validate /
+GenerateNegativePassaageID / utils.dpr_utils.has_answer (tests/golden/make_golden.py) -- CPU only."""
+import json
+import os
+import types
+
+import numpy as np
+import pytest
+
+from ance_amd import ann_data_gen_dpr as dprjob
+from ance_amd import dpr
+
+
+@pytest.fixture(scope="module")
+def g(golden_dir):
+    with open(os.path.join(golden_dir, "dpr_postsearch.json")) as f:
+        j = json.load(f)
+    j["passages"] = {int(k): tuple(v) for k, v in j["passages"].items()}
+    j["I"] = np.asarray(j["I"], dtype=np.int64)
+    return j
+
+
+def test_has_answer_matches_reference(g):
+    m = dpr.AnswerMatcher(g["passages"])
+    for ai, ans in enumerate(g["answers_pool"]):
+        got = [m.has_answer(ans, pid) for pid in range(40)]
+        assert got == g["single"][ai], (ans, got, g["single"][ai])
+
+
+def test_validate_matches_reference(g):
+    m = dpr.AnswerMatcher(g["passages"])
+    nq = g["I"].shape[0]
+    hits = dpr.validate(m, g["answers"], g["I"], np.arange(nq), np.arange(len(g["passages"])))
+    assert hits == g["hits"]
+    assert all(b >= a for a, b in zip(hits, hits[1:]))  # cumulative
+
+
+def test_negatives_match_reference(g):
+    m = dpr.AnswerMatcher(g["passages"])
+    nq = g["I"].shape[0]
+    neg = dpr.generate_negative_passage_ids(m, g["answers"], np.arange(nq), np.arange(len(g["passages"])), g["I"],
+                                            g["pos"], g["negative_sample"])
+    assert {str(k): v for k, v in neg.items()} == g["neg"]
+    # "examined" semantics: never more than negative_sample, positives never kept
+    for q, v in neg.items():
+        assert len(v) <= g["negative_sample"] and g["pos"][q] not in v
+
+
+def test_tokenizer_unicode():
+    assert dpr.tokenize_uncased("Zürich's CAFÉ, naïve!") == dpr.tokenize_uncased("zürich's café, naïve!")
+    assert dpr.tokenize_uncased("U.S. rock&roll") == ["u", ".", "s", ".", "rock", "&", "roll"]
+
+
+def test_checkpoint_discovery_and_flags(tmp_path):
+    tr = tmp_path / "train"
+    a = types.SimpleNamespace(training_dir=str(tr), init_model_dir="/init/dpr.cp")
+    assert dprjob.get_latest_checkpoint(a) == ("/init/dpr.cp", 0)
+    tr.mkdir()
+    (tr / "checkpoint-500").write_text("x")
+    (tr / "checkpoint-1500").write_text("x")
+    (tr / "other").write_text("x")
+    assert dprjob.get_latest_checkpoint(a) == (os.path.join(str(tr), "checkpoint-1500"), 1500)
+    args = dprjob.get_arguments(["--data_dir", "d", "--training_dir", "t", "--init_model_dir", "i", "--model_type", "dpr",
+                                 "--output_dir", "o", "--cache_dir", "c", "--passage_path", "p", "--test_qa_path", "q",
+                                 "--trivia_test_qa_path", "r", "--topk_training", "200", "--negative_sample", "100"])
+    assert args.topk_training == 200 and args.negative_sample == 100 and args.max_seq_length == 128
+
+
+def test_load_data_formats(tmp_path):
+    d = tmp_path / "data"
+    d.mkdir()
+    (d / "pid2offset").write_text("10\t0\n11\t1\n12\t2\n")
+    (d / "train-ann").write_text("0\t1\t['Paris', 'paris france']\n1\t2\t[\"O'Neil\"]\n")
+    (tmp_path / "nq-test.csv").write_text("who?\t['a', 'b']\n")
+    (tmp_path / "trivia-test.csv").write_text("what?\t['c']\n")
+    (tmp_path / "psgs_w100.tsv").write_text("id\ttext\ttitle\n10\t\"He said \"\"hi\"\" in Paris\"\tT0\n11\tsecond\tT1\n12\tthird\tT2\n")
+    a = types.SimpleNamespace(data_dir=str(d), test_qa_path=str(tmp_path), trivia_test_qa_path=str(tmp_path),
+                              passage_path=str(tmp_path))
+    text, pos, ans, ta, tv = dprjob.load_data(a)
+    assert pos == [1, 2] and ans == [["Paris", "paris france"], ["O'Neil"]] and ta == [["a", "b"]] and tv == [["c"]]
+    assert text[0] == ('He said "hi" in Paris', "T0") and text[2] == ("third", "T2")
