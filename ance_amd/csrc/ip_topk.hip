@@ -14,6 +14,9 @@
 // oracle/ip_topk_ref.c.  Ids are exact under (score desc, row asc): corpus rows are scanned in
 // ascending order per split, so "s > threshold" (strict) is the correct admission test.
 #include "common.h"
+#include "topk_common.h"
+#include <stdlib.h>
+#include <string.h>
 
 namespace ance {
 namespace {
@@ -39,40 +42,8 @@ struct ScanParams {
     int tiles_per_split;
     u64 *cand;         // [n_qt * S][TQ][C]
     u64 *part;         // [nq][S][k]
+    const int *only_if;  // optional device flag: the whole launch is a no-op while it reads 0
 };
-
-// k-th largest selection + compaction of one query's candidate list, by one wave.
-// keys are distinct (distinct rows), 0 is the empty sentinel.
-template <int NPL>
-__device__ __forceinline__ int select_topk(const u64 *src, int n_c, int k, u64 *dst, float *tau_out) {
-    const int l = lane_id();
-    u64 keys[NPL];
-#pragma unroll
-    for (int j = 0; j < NPL; ++j) {
-        const int idx = j * 64 + l;
-        keys[j] = (idx < n_c) ? src[idx] : 0ull;
-    }
-    u64 T = 0;
-    for (int bit = 63; bit >= 0; --bit) {
-        const u64 t2 = T | (1ull << bit);
-        int ge = 0;
-#pragma unroll
-        for (int j = 0; j < NPL; ++j) ge += __popcll(__ballot(keys[j] >= t2));
-        if (ge >= k) T = t2;
-    }
-    int base = 0;
-    const u64 lt_mask = (1ull << l) - 1ull;
-#pragma unroll
-    for (int j = 0; j < NPL; ++j) {
-        const bool pr = keys[j] >= T;
-        const u64 m = __ballot(pr);
-        const int pos = base + __popcll(m & lt_mask);
-        if (pr) dst[pos] = keys[j];
-        base += __popcll(m);
-    }
-    *tau_out = key_score(T);
-    return base;
-}
 
 template <int NPL>
 __global__ void __launch_bounds__(SCAN_THREADS, 2) ip_topk_scan_kernel(const ScanParams P) {
@@ -85,6 +56,7 @@ __global__ void __launch_bounds__(SCAN_THREADS, 2) ip_topk_scan_kernel(const Sca
     // Blocks b, b+8, b+16, ... land on the same XCD.  64 consecutive blocks of one XCD form a
     // group of GQ = 64/S query tiles x S splits: they stream the same corpus ranges at the same
     // time (X tiles shared through that XCD's L2) and keep only GQ query tiles hot.
+    if (P.only_if && *P.only_if == 0) return;
     const int b = blockIdx.x;
     const int xcd = b & 7, jx = b >> 3;
     const int gq = 64 / P.S;
@@ -254,64 +226,6 @@ __global__ void __launch_bounds__(SCAN_THREADS, 2) ip_topk_scan_kernel(const Sca
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// Bitonic sort (descending) of P2 keys in LDS by one 256-thread block.
-__device__ __forceinline__ void bitonic_sort_desc(u64 *s, int P2) {
-    const int tid = threadIdx.x, nt = blockDim.x;
-    for (int size = 2; size <= P2; size <<= 1) {
-        for (int stride = size >> 1; stride > 0; stride >>= 1) {
-            for (int i = tid; i < (P2 >> 1); i += nt) {
-                const int lo = 2 * i - (i & (stride - 1));
-                const int hi = lo + stride;
-                const bool desc = (lo & size) == 0;
-                const u64 a = s[lo], b2 = s[hi];
-                if ((a < b2) == desc) {
-                    s[lo] = b2;
-                    s[hi] = a;
-                }
-            }
-            __syncthreads();
-        }
-    }
-}
-
-// FROM_DI = false: entries are packed keys [nq][m]; true: entries are (D, I) parts [n_parts][nq][k]
-template <bool FROM_DI>
-__global__ void __launch_bounds__(256) topk_finalize_kernel(const u64 *keys, const float *pd, const int64_t *pi,
-                                                            int n_parts, int64_t nq, int m, int P2, int k,
-                                                            int64_t row_base, float *out_d, int64_t *out_i) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    u64 *s = reinterpret_cast<u64 *>(smem);
-    const int64_t qi = blockIdx.x;
-    for (int i = threadIdx.x; i < P2; i += blockDim.x) {
-        u64 v = 0ull;
-        if (i < m) {
-            if constexpr (FROM_DI) {
-                const int p = i / k, r = i - p * k;
-                const size_t o = ((size_t)p * nq + qi) * k + r;
-                const int64_t id = pi[o];
-                if (id >= 0) v = pack_key(pd[o], (uint32_t)id);
-            } else {
-                v = keys[(size_t)qi * m + i];
-            }
-        }
-        s[i] = v;
-    }
-    __syncthreads();
-    bitonic_sort_desc(s, P2);
-    for (int i = threadIdx.x; i < k; i += blockDim.x) {
-        const u64 v = (i < P2) ? s[i] : 0ull;
-        const size_t o = (size_t)qi * k + i;
-        if (v == 0ull) {
-            out_d[o] = -FLT_MAX;
-            out_i[o] = -1;
-        } else {
-            out_d[o] = key_score(v);
-            out_i[o] = row_base + (int64_t)key_row(v);
-        }
-    }
-}
-
 struct Plan {
     int npl;        // candidate buffer = 64 * npl entries per query
     int S;          // corpus splits
@@ -320,12 +234,6 @@ struct Plan {
     int tiles_per_split;
     size_t cand_bytes, part_bytes;
 };
-
-inline int next_pow2(int v) {
-    int p = 1;
-    while (p < v) p <<= 1;
-    return p;
-}
 
 bool make_plan(int64_t n, int64_t nq, int k, Plan *pl) {
     if (k < 1 || k > ANCE_TOPK_MAX_K || n < 0 || n >= (1ll << 32) || nq < 0) return false;
@@ -347,18 +255,103 @@ bool make_plan(int64_t n, int64_t nq, int k, Plan *pl) {
 }
 
 }  // namespace
+
+int launch_finalize_keys(const u64 *keys, int64_t nq, int m, int k, int64_t row_base, float *out_d, int64_t *out_i,
+                         hipStream_t st, const int *sel_flag, const u64 *alt_keys, int alt_m) {
+    const int P2 = next_pow2(m > alt_m ? m : alt_m);
+    static int attr_p2 = 0;
+    if (P2 > attr_p2) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(topk_finalize_kernel<false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)(P2 * sizeof(u64))) != hipSuccess)
+            return check_launch("topk_finalize attr");
+        attr_p2 = P2;
+    }
+    ProfScope pf(PC_FINALIZE, st);
+    hipLaunchKernelGGL(topk_finalize_kernel<false>, dim3((unsigned)nq), dim3(256), P2 * sizeof(u64), st, keys,
+                       (const float *)nullptr, (const int64_t *)nullptr, 1, nq, m, P2, k, row_base, out_d, out_i, sel_flag,
+                       alt_keys, alt_m);
+    return ANCE_OK;
+}
+
+namespace {
+int launch_scan(const Plan &pl, const float *d_x, int64_t n, const float *q, int64_t nqc, int d, int k, u64 *cand, u64 *part,
+                const int *only_if, hipStream_t st) {
+    auto scan = pl.npl == 8 ? ip_topk_scan_kernel<8> : (pl.npl == 16 ? ip_topk_scan_kernel<16> : ip_topk_scan_kernel<32>);
+    static bool attr_done[3] = {false, false, false};
+    const int ai = pl.npl == 8 ? 0 : (pl.npl == 16 ? 1 : 2);
+    if (!attr_done[ai]) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(scan), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)SCAN_LDS_BYTES) != hipSuccess)
+            return check_launch("ip_topk_scan attr");
+        attr_done[ai] = true;
+    }
+    ScanParams P;
+    P.x = d_x; P.q = q; P.n = (uint32_t)n; P.nq = (uint32_t)nqc; P.d = d; P.k = k; P.S = pl.S;
+    P.n_qt = (int)((nqc + TQ - 1) / TQ); P.n_tiles_p = pl.n_tiles_p; P.tiles_per_split = pl.tiles_per_split;
+    P.cand = cand; P.part = part; P.only_if = only_if;
+    const int gq = 64 / pl.S;
+    const int groups = (P.n_qt + gq - 1) / gq;
+    const unsigned blocks = (unsigned)((groups + 7) / 8 * 8) * 64u;
+    ProfScope ps(PC_SCAN, st, only_if ? 0.0 : 2.0 * (double)nqc * (double)n * (double)d);
+    hipLaunchKernelGGL(scan, dim3(blocks), dim3(SCAN_THREADS), SCAN_LDS_BYTES, st, P);
+    return ANCE_OK;
+}
+}  // namespace
+
+size_t exact_scan_fallback_bytes(int64_t n, int64_t nq, int k) {
+    Plan pl;
+    if (!make_plan(n, nq, k, &pl) || nq > pl.qc) return 0;
+    return pl.part_bytes + pl.cand_bytes + 256;
+}
+
+int exact_scan_fallback(const float *d_x, int64_t n, const float *d_q, int64_t nq, int d, int k, void *d_ws, const int *only_if,
+                        const u64 **part_out, int *m_out, hipStream_t st) {
+    Plan pl;
+    if (!make_plan(n, nq, k, &pl) || nq > pl.qc) {
+        set_last_error("exact_scan_fallback: chunk too large");
+        return ANCE_E_INVALID;
+    }
+    u64 *part = reinterpret_cast<u64 *>(align_up((uintptr_t)d_ws, 256));
+    u64 *cand = reinterpret_cast<u64 *>((char *)part + pl.part_bytes);
+    *part_out = part;
+    *m_out = pl.S * k;
+    return launch_scan(pl, d_x, n, d_q, nq, d, k, cand, part, only_if, st);
+}
+
 }  // namespace ance
 
 using namespace ance;
 
-extern "C" size_t ance_ip_topk_workspace_bytes(int64_t n, int64_t nq, int k) {
-    Plan pl;
-    if (!make_plan(n, nq, k, &pl)) return 0;
-    return pl.part_bytes + pl.cand_bytes + 256;
+namespace ance {
+size_t ip_topk_fast_workspace_bytes(int64_t n, int64_t nq, int d, int k);
+int ip_topk_fast(const float *d_x, int64_t n, int64_t row_base, const float *d_q, int64_t nq, int d, int k, float *d_out_d,
+                 int64_t *d_out_i, void *d_workspace, size_t workspace_bytes, hipStream_t st);
 }
 
-extern "C" int ance_ip_topk(const float *d_x, int64_t n, int64_t row_base, const float *d_q, int64_t nq, int d, int k,
-                            float *d_out_d, int64_t *d_out_i, void *d_workspace, size_t workspace_bytes, void *stream) {
+// ANCE_SEARCH=exact forces the fp32-MFMA scan everywhere (A/B and cross-checks); default: the
+// two-precision path whenever the shape is eligible (d % 64 == 0, k <= 256, n >= 4096).
+static bool fast_enabled() {
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("ANCE_SEARCH");
+        v = (e && !strcmp(e, "exact")) ? 0 : 1;
+    }
+    return v == 1;
+}
+
+extern "C" size_t ance_ip_topk_workspace_bytes(int64_t n, int64_t nq, int d, int k) {
+    Plan pl;
+    if (!make_plan(n, nq, k, &pl)) return 0;
+    size_t need = pl.part_bytes + pl.cand_bytes + 256;
+    if (fast_enabled()) {
+        const size_t f = ip_topk_fast_workspace_bytes(n, nq, d, k);
+        if (f > need) need = f;
+    }
+    return need;
+}
+
+static int ip_topk_exact_scan(const float *d_x, int64_t n, int64_t row_base, const float *d_q, int64_t nq, int d, int k,
+                              float *d_out_d, int64_t *d_out_i, void *d_workspace, size_t workspace_bytes, void *stream) {
     Plan pl;
     if (!make_plan(n, nq, k, &pl) || d < 4 || (d & 3) || !d_out_d || !d_out_i || (nq > 0 && !d_q) || (n > 0 && !d_x) ||
         ((uintptr_t)d_x & 15) || ((uintptr_t)d_q & 15)) {
@@ -374,45 +367,23 @@ extern "C" int ance_ip_topk(const float *d_x, int64_t n, int64_t row_base, const
     u64 *part = reinterpret_cast<u64 *>(align_up((uintptr_t)d_workspace, 256));
     u64 *cand = reinterpret_cast<u64 *>((char *)part + pl.part_bytes);
 
-    auto scan = pl.npl == 8 ? ip_topk_scan_kernel<8> : (pl.npl == 16 ? ip_topk_scan_kernel<16> : ip_topk_scan_kernel<32>);
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(scan), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)SCAN_LDS_BYTES) != hipSuccess)
-        return check_launch("ip_topk_scan attr");
     const int m = pl.S * k;
-    const int P2 = next_pow2(m);
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(topk_finalize_kernel<false>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)(P2 * sizeof(u64))) != hipSuccess)
-        return check_launch("topk_finalize attr");
-
     for (int64_t q0 = 0; q0 < nq; q0 += pl.qc) {
         const int64_t nqc = (nq - q0) < pl.qc ? (nq - q0) : pl.qc;
-        ScanParams P;
-        P.x = d_x;
-        P.q = d_q + (size_t)q0 * d;
-        P.n = (uint32_t)n;
-        P.nq = (uint32_t)nqc;
-        P.d = d;
-        P.k = k;
-        P.S = pl.S;
-        P.n_qt = (int)((nqc + TQ - 1) / TQ);
-        P.n_tiles_p = pl.n_tiles_p;
-        P.tiles_per_split = pl.tiles_per_split;
-        P.cand = cand;
-        P.part = part;
-        const int gq = 64 / pl.S;
-        const int groups = (P.n_qt + gq - 1) / gq;
-        const int groups_pad = (groups + 7) / 8 * 8;
-        const unsigned blocks = (unsigned)groups_pad * 64u;
-        {
-            ProfScope ps(PC_SCAN, st, 2.0 * (double)nqc * (double)n * (double)d);
-            hipLaunchKernelGGL(scan, dim3(blocks), dim3(SCAN_THREADS), SCAN_LDS_BYTES, st, P);
-        }
-        ProfScope pf(PC_FINALIZE, st);
-        hipLaunchKernelGGL(topk_finalize_kernel<false>, dim3((unsigned)nqc), dim3(256), P2 * sizeof(u64), st, part,
-                           (const float *)nullptr, (const int64_t *)nullptr, 1, nqc, m, P2, k, row_base,
-                           d_out_d + (size_t)q0 * k, d_out_i + (size_t)q0 * k);
+        int rc = launch_scan(pl, d_x, n, d_q + (size_t)q0 * d, nqc, d, k, cand, part, nullptr, st);
+        if (rc) return rc;
+        rc = launch_finalize_keys(part, nqc, m, k, row_base, d_out_d + (size_t)q0 * k, d_out_i + (size_t)q0 * k, st);
+        if (rc) return rc;
     }
     return check_launch("ance_ip_topk");
+}
+
+extern "C" int ance_ip_topk(const float *d_x, int64_t n, int64_t row_base, const float *d_q, int64_t nq, int d, int k,
+                            float *d_out_d, int64_t *d_out_i, void *d_workspace, size_t workspace_bytes, void *stream) {
+    if (fast_enabled() && nq > 0 && d_x && d_q && d_out_d && d_out_i && d_workspace && !((uintptr_t)d_x & 15) &&
+        !((uintptr_t)d_q & 15) && ip_topk_fast_workspace_bytes(n, nq, d, k) > 0)
+        return ip_topk_fast(d_x, n, row_base, d_q, nq, d, k, d_out_d, d_out_i, d_workspace, workspace_bytes, (hipStream_t)stream);
+    return ip_topk_exact_scan(d_x, n, row_base, d_q, nq, d, k, d_out_d, d_out_i, d_workspace, workspace_bytes, stream);
 }
 
 extern "C" size_t ance_topk_merge_workspace_bytes(int n_parts, int64_t nq, int k) {
@@ -439,6 +410,7 @@ extern "C" int ance_topk_merge(const float *d_parts_d, const int64_t *d_parts_i,
         return check_launch("topk_merge attr");
     ProfScope pf(PC_FINALIZE, (hipStream_t)stream);
     hipLaunchKernelGGL(topk_finalize_kernel<true>, dim3((unsigned)nq), dim3(256), P2 * sizeof(u64), (hipStream_t)stream,
-                       (const u64 *)nullptr, d_parts_d, d_parts_i, n_parts, nq, m, P2, k, (int64_t)0, d_out_d, d_out_i);
+                       (const u64 *)nullptr, d_parts_d, d_parts_i, n_parts, nq, m, P2, k, (int64_t)0, d_out_d, d_out_i,
+                       (const int *)nullptr, (const u64 *)nullptr, 0);
     return check_launch("ance_topk_merge");
 }

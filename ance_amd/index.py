@@ -87,7 +87,7 @@ class FlatIPIndex:
         I = torch.empty((nq, k), dtype=torch.int64, device=self.device)
         if nq == 0:
             return D, I
-        need = L.ance_ip_topk_workspace_bytes(n, nq, k)
+        need = L.ance_ip_topk_workspace_bytes(n, nq, self.dp, k)
         if need == 0:
             raise _lib.AnceLibraryError("ance_ip_topk: unsupported (n=%d, nq=%d, k=%d)" % (n, nq, k))
         if self._ws is None or self._ws.numel() < need:

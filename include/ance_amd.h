@@ -60,8 +60,8 @@ int ance_profile_read(double *ms, double *work, long long *count, int n);
 
 #define ANCE_TOPK_MAX_K 1792
 
-/* Bytes of scratch ance_ip_topk needs for (n rows, nq queries, k).  0 if unsupported. */
-size_t ance_ip_topk_workspace_bytes(int64_t n, int64_t nq, int k);
+/* Bytes of scratch ance_ip_topk needs for (n rows, nq queries, dimension d, k).  0 if unsupported. */
+size_t ance_ip_topk_workspace_bytes(int64_t n, int64_t nq, int d, int k);
 
 /*
  * Exact inner-product top-k of nq queries against one shard of n rows.
@@ -71,6 +71,11 @@ size_t ance_ip_topk_workspace_bytes(int64_t n, int64_t nq, int k);
  *   d_out_d   float32 [nq, k] scores, canonical order; -FLT_MAX where fewer than k rows exist
  *   d_out_i   int64   [nq, k] global row ids; -1 where fewer than k rows exist
  * Requires n < 2^32, 1 <= k <= ANCE_TOPK_MAX_K.
+ *
+ * Two kernels produce the same bits: an fp32-MFMA scan (any shape), and -- when d % 64 == 0,
+ * k <= 256 and n >= 4096 -- a two-precision path: fp16 MFMA scores filter the corpus under a
+ * rigorous error slack, every survivor is re-scored with the exact fp32 fmaf chain.  Both need
+ * |x|, |q| < 65504 for the second.  ANCE_SEARCH=exact in the environment forces the first.
  */
 int ance_ip_topk(const float *d_x, int64_t n, int64_t row_base, const float *d_q, int64_t nq, int d, int k,
                  float *d_out_d, int64_t *d_out_i, void *d_workspace, size_t workspace_bytes, void *stream);

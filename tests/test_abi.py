@@ -35,10 +35,10 @@ def test_library_loads_and_exports_everything():
 
 def test_workspace_queries_are_pure():
     L = _lib.lib()
-    assert L.ance_ip_topk_workspace_bytes(10000, 1000, 200) > 0
-    assert L.ance_ip_topk_workspace_bytes(10000, 1000, 0) == 0          # k out of range
-    assert L.ance_ip_topk_workspace_bytes(10000, 1000, 5000) == 0
-    assert L.ance_ip_topk_workspace_bytes(1 << 33, 10, 10) == 0         # n >= 2^32
+    assert L.ance_ip_topk_workspace_bytes(10000, 1000, 768, 200) > 0
+    assert L.ance_ip_topk_workspace_bytes(10000, 1000, 768, 0) == 0          # k out of range
+    assert L.ance_ip_topk_workspace_bytes(10000, 1000, 768, 5000) == 0
+    assert L.ance_ip_topk_workspace_bytes(1 << 33, 10, 768, 10) == 0         # n >= 2^32
     d = _lib.AnceEncoderDesc(arch=0, n_layers=12, hidden=768, n_heads=12, intermediate=3072, vocab_size=50265,
                              max_position=514, pad_token_id=1, ln_eps=1e-5, has_head=1, max_seq_len=512, max_tokens=32768)
     assert L.ance_encoder_weight_bytes(ctypes.byref(d)) > 300e6

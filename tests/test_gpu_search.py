@@ -180,3 +180,40 @@ def test_properties_at_scale():
         kth_s, kth_i = D[r, -1], I[r, -1]
         better = (S[j] > kth_s) | ((S[j] == kth_s) & (samp.numpy() < kth_i))
         assert set(samp.numpy()[better].tolist()) <= set(I[r].tolist())
+
+
+def test_clustered_scores_every_row_is_a_candidate():
+    """Rows differ by ~1e-3 noise around one vector: all scores lie far inside the fp16 filter's slack,
+    so the two-precision path must re-score everything exactly -- and still return the exact lists."""
+    from oracle import synth
+    rng = np.random.default_rng(21)
+    c = synth.ln_rows(rng, 1)[0]
+    n = 8192
+    x = (c[None, :] + 1e-3 * rng.standard_normal((n, 768))).astype(np.float32)
+    x[4000] = x[17]
+    q = np.concatenate([synth.ln_rows(rng, 40), c[None, :], -c[None, :]]).astype(np.float32)
+    _check_exact("clustered", x, q, 200)
+
+
+def test_tiny_and_mixed_magnitudes():
+    """fp16-subnormal-sized corpus rows, and a corpus mixing magnitudes over six decades."""
+    from oracle import synth
+    rng = np.random.default_rng(22)
+    x = synth.ln_rows(rng, 6000) * np.float32(1e-5)
+    q = synth.ln_rows(rng, 48)
+    _check_exact("tiny", x.astype(np.float32), q, 100)
+    scale = (10.0 ** rng.uniform(-4, 2, size=(6000, 1))).astype(np.float32)
+    _check_exact("mixed", (synth.ln_rows(rng, 6000) * scale).astype(np.float32), q, 200)
+
+
+def test_fast_path_large_query_block():
+    """20,000 queries x 60,000 rows: several query chunks / tiles per launch of the fast path."""
+    from oracle import search_ref, synth
+    rng = np.random.default_rng(23)
+    x = synth.ln_rows(rng, 60000)
+    q = synth.ln_rows(rng, 20000)
+    D, I = _search(x, q, 100)
+    pick = rng.integers(0, 20000, 300)
+    Do, Io = search_ref.flat_ip_topk_chain(x, q[pick], 100)
+    assert np.array_equal(I[pick], Io) and np.array_equal(D[pick], Do)
+    assert np.all(D[:, 1:] <= D[:, :-1])

@@ -70,7 +70,7 @@ static int run_search(int64_t n, int64_t nq, int k, int reps) {
     CK(hipMemcpy(dq, q.data(), (size_t)nq * d * 4, hipMemcpyHostToDevice));
     CK(hipMalloc(&dD, (size_t)nq * k * 4));
     CK(hipMalloc(&dI, (size_t)nq * k * 8));
-    const size_t wsb = ance_ip_topk_workspace_bytes(n, nq, k);
+    const size_t wsb = ance_ip_topk_workspace_bytes(n, nq, d, k);
     CK(hipMalloc(&ws, wsb));
     hipStream_t st;
     CK(hipStreamCreate(&st));
