@@ -5,7 +5,7 @@ cd "$(dirname "$0")/.."
 mkdir -p gpurun_out/pmc
 export TMPDIR=/tmp
 export LD_LIBRARY_PATH=/opt/rocm/lib:${LD_LIBRARY_PATH:-}
-S="tools/abi_probe search ${PMC_N:-8841823} ${PMC_NQ:-4096} 200 2"
+S="tools/abi_probe search ${PMC_N:-8841823} ${PMC_NQ:-32768} 200 2"
 E="tools/abi_probe encode ${PMC_NP:-16384} 128 12 2 65536"
 echo "== plain runs"; timeout 300 $S; timeout 300 $E
 for what in search encode; do
