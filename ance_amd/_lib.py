@@ -55,6 +55,14 @@ SYMBOLS = {
                                        ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
                                        ctypes.c_void_p]),
     "ance_encoder_flops_per_sequence": (ctypes.c_double, [ctypes.c_int]),
+    "ance_host_py_shuffle": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]),
+    "ance_host_select_negatives": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int,
+                                                  ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
+                                                  ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
+                                                  ctypes.c_void_p, ctypes.POINTER(ctypes.c_double)]),
+    "ance_host_write_ann_training": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
+                                                    ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                                    ctypes.c_int, ctypes.POINTER(ctypes.c_int64)]),
     "ance_debug_gemm": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
                                        ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                        ctypes.c_void_p]),

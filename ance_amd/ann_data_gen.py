@@ -260,8 +260,10 @@ def generate_new_ann(args, output_num, checkpoint_path, training_query_positive_
         dev_ndcg, n_dev_eval = negatives.eval_dev_query(dev_q2id, p2id, dev_query_positive_id, dev_I)
         print("Rank:" + str(dist.rank) + " --- ANN NDCG@10:" + str(dev_ndcg))
         effective_q_id = set(q2id.tolist())
-        neg = negatives.generate_negative_passage_ids(q2id, p2id, training_query_positive_id, I, effective_q_id,
-                                                      args.negative_sample, args.ann_measure_topk_mrr, rank=dist.rank)
+        neg = negatives.select_negatives(q2id, p2id, training_query_positive_id, I, effective_q_id,
+                                         args.negative_sample, args.ann_measure_topk_mrr)
+        if args.ann_measure_topk_mrr:
+            print("Rank:" + str(dist.rank) + " --- ANN MRR:" + str(neg.mrr))
         logger.info("***** Construct ANN Triplet *****")
         os.makedirs(args.output_dir, exist_ok=True)
         negatives.write_ann_files(args.output_dir, output_num, I.shape[0], q2id, effective_q_id,

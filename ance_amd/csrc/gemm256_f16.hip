@@ -27,6 +27,7 @@
 #include "common.h"
 #include "gemm_f16.h"
 #include "gemm256_epilogue.h"
+#include "pipe256.h"
 #include <string.h>
 
 namespace ance {
@@ -41,33 +42,12 @@ constexpr size_t G256_LDS_BYTES = (size_t)2 * STAGE_HALVES * sizeof(_Float16);  
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void glb_void_t;
 
-template <int EPI, bool ABLATE>
-__global__ void __launch_bounds__(G256_THREADS, 2) gemm256_f16_kernel(const GemmArgs G) {
-    extern __shared__ __attribute__((aligned(16))) float smem_f[];
-    _Float16 *smem = reinterpret_cast<_Float16 *>(smem_f);
-
-    const int NT = G.N / TN, MT = G.M / TM;
-    // XCD-aware tile order (speed only): blocks b, b+8, ... share an XCD.  The dimension with more
-    // tiles is dealt round-robin to the XCDs, the other one is swept fastest, so the panel of the
-    // outer dimension stays in that XCD's L2 while the inner panels stream through it.
-    const int b = blockIdx.x, xcd = b & 7, jx = b >> 3;
-    int mt, nt;
-    if (MT >= NT) {
-        mt = (jx / NT) * 8 + xcd;
-        nt = jx % NT;
-    } else {
-        nt = (jx / MT) * 8 + xcd;
-        mt = jx % MT;
-    }
-    if (mt >= MT || nt >= NT) return;
-    const int m0 = mt * TM, n0 = nt * TN;
-
-    const int tid = threadIdx.x;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int l = tid & 63, g = l >> 5, i = l & 31;
-    const int wm = w >> 2;  // 2 x 128 output rows m
-    const int wn = w & 3;   // 4 x 64 output cols n
-
+// Two-phase loop (one barrier + full vmcnt drain per K-tile): the structure the ping-pong pipeline
+// replaced.  Kept only behind ance_debug_gemm's ablation switches (1: no loads after the first tile,
+// 2: no MFMA, 4: every block loads tile (0,0), 8: none -- plain A/B reference).
+__device__ __forceinline__ void two_phase_loop(const GemmArgs &G, f32x16 (&acc)[2][4], _Float16 *smem, int m0, int n0, int w,
+                                               int l) {
+    const int g = l >> 5, i = l & 31, wm = w >> 2, wn = w & 3;
     // ---- staging ------------------------------------------------------------------------------
     // LDS image of an operand tile: row r (128 B), 16-byte chunk c stored in slot c ^ ((r >> 1) & 7).
     // One wave-instruction covers 8 rows x 8 chunks = 1 KiB; wave w handles row groups w, w+8, ...
@@ -78,7 +58,7 @@ __global__ void __launch_bounds__(G256_THREADS, 2) gemm256_f16_kernel(const Gemm
     for (int j = 0; j < 4; ++j) {
         const int row = (j * 8 + w) * 8 + rg;
         const int ch = slot ^ ((row >> 1) & 7);
-        const int ml = (ABLATE && (G.debug_mode & 4)) ? 0 : m0, nl = (ABLATE && (G.debug_mode & 4)) ? 0 : n0;  // ablation: L2-resident operands
+        const int ml = ((G.debug_mode & 4)) ? 0 : m0, nl = ((G.debug_mode & 4)) ? 0 : n0;  // ablation: L2-resident operands
         srcA[j] = G.A + (size_t)(ml + row) * G.lda + ch * 8;
         srcB[j] = G.B + (size_t)(nl + row) * G.ldb + ch * 8;
     }
@@ -107,19 +87,13 @@ __global__ void __launch_bounds__(G256_THREADS, 2) gemm256_f16_kernel(const Gemm
         msw[x] = (mrow[x] >> 1) & 7;
     }
 
-    f32x16 acc[2][4];
-#pragma unroll
-    for (int x = 0; x < 2; ++x)
-#pragma unroll
-        for (int y = 0; y < 4; ++y) acc[x][y] = f32x16{0};
-
     const int NK = G.K / TK;
     stage_issue(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     for (int kt = 0; kt < NK; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < NK && !(ABLATE && (G.debug_mode & 1))) stage_issue(kt + 1, buf ^ 1);
+        if (kt + 1 < NK && !((G.debug_mode & 1))) stage_issue(kt + 1, buf ^ 1);
         const _Float16 *sa = smem + buf * STAGE_HALVES;  // A-matrix rows (m)
         const _Float16 *sb = sa + OPER_HALVES;           // B-matrix rows (n)
         // fragments of k-step s+1 are requested before the MFMAs of k-step s are issued
@@ -134,7 +108,7 @@ __global__ void __launch_bounds__(G256_THREADS, 2) gemm256_f16_kernel(const Gemm
                 fm[set][y] = *reinterpret_cast<const f16x8 *>(sa + mrow[y] * TK + ((ch ^ msw[y]) * 8));
         };
         auto mfma_step = [&](int set) {
-            if (ABLATE && (G.debug_mode & 2)) {  // ablation: keep the LDS reads alive, skip the matrix pipe
+            if ((G.debug_mode & 2)) {  // ablation: keep the LDS reads alive, skip the matrix pipe
 #pragma unroll
                 for (int x = 0; x < 2; ++x) asm volatile("" ::"v"(fn[set][x]));
 #pragma unroll
@@ -158,7 +132,59 @@ __global__ void __launch_bounds__(G256_THREADS, 2) gemm256_f16_kernel(const Gemm
         __syncthreads();
     }
 
-    gemm256_epilogue<EPI>(G, acc, smem_f, m0, n0, w, l);
+}
+
+template <int EPI, bool ABLATE>
+__global__ void __launch_bounds__(G256_THREADS, 2) gemm256_f16_kernel(const GemmArgs G) {
+    extern __shared__ __attribute__((aligned(16))) float smem_f[];
+    _Float16 *smem = reinterpret_cast<_Float16 *>(smem_f);
+
+    const int NT = G.N / TN, MT = G.M / TM;
+    // XCD-aware tile order (speed only): blocks b, b+8, ... share an XCD.  The dimension with more
+    // tiles is dealt round-robin to the XCDs, the other one is swept fastest, so the panel of the
+    // outer dimension stays in that XCD's L2 while the inner panels stream through it.
+    const int b = blockIdx.x, xcd = b & 7, jx = b >> 3;
+    int mt, nt;
+    if (MT >= NT) {
+        mt = (jx / NT) * 8 + xcd;
+        nt = jx % NT;
+    } else {
+        nt = (jx / MT) * 8 + xcd;
+        mt = jx % MT;
+    }
+    if (mt >= MT || nt >= NT) return;
+    const int m0_ = mt * TM, n0_ = nt * TN;
+
+    const int tid = threadIdx.x;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l = tid & 63;  // wave w: output rows m wm*128.. (wm = w >> 2), columns n wn*64.. (wn = w & 3)
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 4; ++y) acc[x][y] = f32x16{0};
+
+    if (!ABLATE || (G.debug_mode & 16)) {
+        // product path: ping-pong pipeline of pipe256.h (debug_mode 16 + bits: its ablations)
+        Pipe256T<ABLATE> P;
+        P.init(smem, w, l);
+        P.dbg = G.debug_mode;
+        const int m0 = (ABLATE && (G.debug_mode & 4)) ? 0 : m0_, n0 = (ABLATE && (G.debug_mode & 4)) ? 0 : n0_;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int r = Pipe256::stage_row(w, l, j), ch = Pipe256::stage_chunk(r, l);
+                P.src[h][j] = G.A + (size_t)(m0 + pipe_a_tile_row(h, r)) * G.lda + ch;
+                P.src[2 + h][j] = G.B + (size_t)(n0 + pipe_b_tile_row(h, r)) * G.ldb + ch;
+            }
+        P.run(G.K / TK, acc);
+    } else {
+        two_phase_loop(G, acc, smem, m0_, n0_, w, l);
+    }
+
+    gemm256_epilogue<EPI>(G, acc, smem_f, m0_, n0_, w, l);
 }
 
 template <bool ABLATE>
@@ -187,12 +213,12 @@ int launch256(int epi, const GemmArgs &G, hipStream_t st) {
 }  // namespace
 
 bool gemm256_applicable(const GemmArgs &G) {
-    return G.M > 0 && G.N > 0 && G.K > 0 && G.M % TM == 0 && G.N % TN == 0 && G.K % TK == 0;
+    return G.M > 0 && G.N > 0 && G.K >= 2 * TK && G.M % TM == 0 && G.N % TN == 0 && G.K % TK == 0;
 }
 
 int launch_gemm_f16(int epi, const GemmArgs &G, hipStream_t st) {
     if (!gemm256_applicable(G)) {
-        set_last_error("gemm_f16: M,N must be multiples of 256 and K of 64");
+        set_last_error("gemm_f16: M,N must be multiples of 256 and K a multiple of 64, >= 128");
         return ANCE_E_INVALID;
     }
     return G.debug_mode ? launch256<true>(epi, G, st) : launch256<false>(epi, G, st);

@@ -348,6 +348,10 @@ bool make_fast_plan(int64_t n, int64_t nq, int d, int k, FastPlan *pl) {
     pl->qc = qct * FQ;
     int S = 1;
     while (qct * S < 512 && S < 32) S <<= 1;
+    if (const char *e = getenv("ANCE_FAST_SPLITS")) {  // tuning knob (power of two, 1..32)
+        const int v = atoi(e);
+        if (v >= 1 && v <= 32 && (v & (v - 1)) == 0) S = v;
+    }
     while (S > 1 && (S * 8 > pl->n_tiles_p || next_pow2(S * k) > 8192)) S >>= 1;
     pl->S = S;
     pl->tiles_per_split = (pl->n_tiles_p + S - 1) / S;

@@ -1,0 +1,169 @@
+// Ping-pong main loop of the 256 x 256 x 64 fp16 MFMA tile (gfx950), shared by the encoder GEMM
+// (gemm256_f16.hip) and the search filter (ip_topk_fast.hip).
+//
+//   acc[x][y] += sum_k  B[n][k] * A[m][k]      n = wn*64 + x*32 + (C-layout row)   m = wm*128 + y*32 + lane&31
+//
+// 8 waves (2 along m x 4 along n), 128 KiB of LDS = 2 K-tile buffers x 4 half-tiles of 128 rows x
+// 64 halves (16 KiB each): A-half h holds the 64-row blocks {h, h+2} of the A tile (so a wave's
+// fragments y = 0,1 come from A-half 0 and y = 2,3 from A-half 1), B-half h holds the 32-row
+// blocks {h, h+2, h+4, h+6} of the B tile (x = h).  A K-tile is consumed in four phases, one
+// 64 x 32 output quadrant of every wave each:
+//
+//   phase c0: read A-half0 + B-half0   MFMA acc[0][0..1]      stage B-half1 of tile t+1
+//   phase c1: read B-half1             MFMA acc[1][0..1]      stage A-half1 of tile t+1
+//   phase c2: read A-half1             MFMA acc[1][2..3]      stage A-half0 of tile t+2
+//   phase c3: (B-half0 kept in VGPRs)  MFMA acc[0][2..3]      stage B-half0 of tile t+2
+//
+// Every phase is  { ds_reads ; 2 x global_load_lds ; s_waitcnt vmcnt(8) }  s_barrier  { 8 MFMA }
+// s_barrier.  The four waves with wm = 1 run one barrier behind the four with wm = 0, so on every
+// SIMD one wave is in its MFMA half-phase while the other one reads LDS and issues loads: the
+// matrix pipe never waits for a ds_read, and staged half-tiles stay in flight across barriers
+// (5-6 phases ahead, counted vmcnt, never 0 in steady state).
+//
+// Hazards (slot = interval between two barriers; wm=0 reads in slot 2p, wm=1 in slot 2p+1):
+//   RAW  a half-tile read in phase p was staged in phase p-5 (or p-6); every wave retires its own
+//        pieces with vmcnt(8) at the end of its read half-phase p-1, i.e. before the barrier that
+//        precedes the first read.
+//   WAR  a half-tile read in phase p is restaged in phase p+2 at the earliest: the last ds_read of
+//        it (wm=1, slot 2p+1) has returned before that wave's MFMAs of slot 2p+2 finish (they consume
+//        it), and the barrier ending slot 2p+2 precedes the first restage (wm=0, slot 2p+4).
+// Needs NK >= 2 K-tiles.  The last two tiles are peeled (nothing left to stage, smaller counts).
+#pragma once
+#include "common.h"
+
+namespace ance {
+
+typedef __attribute__((address_space(3))) void pipe_lds_t;
+typedef const __attribute__((address_space(1))) void pipe_glb_t;
+
+constexpr int PIPE_HALF_HALVES = 128 * 64;            // one half-tile: 16 KiB
+constexpr int PIPE_BUF_HALVES = 4 * PIPE_HALF_HALVES;  // A0 A1 B0 B1: 64 KiB
+constexpr size_t PIPE_LDS_BYTES = (size_t)2 * PIPE_BUF_HALVES * sizeof(_Float16);
+
+#define PIPE_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+
+// Row of the 256-row operand tile held at row r of half-tile h.
+__device__ __forceinline__ int pipe_a_tile_row(int h, int r) { return (((r >> 6) * 2 + h) << 6) + (r & 63); }
+__device__ __forceinline__ int pipe_b_tile_row(int h, int r) { return (((r >> 5) * 2 + h) << 5) + (r & 31); }
+
+// DBG compiles measurement ablations in (dbg bit 0: always re-read K-tiles 0/1, bit 1: no MFMA, bit 3: no staging);
+// the product instantiation is Pipe256<false>.
+template <bool DBG = false>
+struct Pipe256T {
+    // per-lane source pointers at k = 0 of the two 1 KiB pieces this wave stages per half-tile:
+    // piece j covers half-tile rows (w + 8 j) * 8 + (lane >> 3), LDS slot lane & 7, and must point at
+    // 16-byte chunk  (lane & 7) ^ ((row >> 1) & 7)  of that row (the XOR swizzle lives in the source
+    // address because the LDS image of an LDS-DMA is lane-linear).
+    const _Float16 *src[4][2];  // [A0 A1 B0 B1][piece]
+    _Float16 *smem;
+    int w, dbg = 0;
+    int ra[2], rb, kx[4];  // per-lane read offsets (halves)
+    f16x8 fa[2][4], fb[2][4];
+
+    __device__ __forceinline__ void init(_Float16 *smem_, int w_, int l) {
+        smem = smem_;
+        w = w_;
+        const int g = l >> 5, i = l & 31, wm = w >> 2, wn = w & 3;
+        const int c0 = g ^ ((i >> 1) & 7);  // row offsets below are multiples of 16: swizzle depends on i only
+#pragma unroll
+        for (int s = 0; s < 4; ++s) kx[s] = (c0 ^ (2 * s)) * 8;
+        ra[0] = (wm * 64 + i) * 64;
+        ra[1] = (wm * 64 + 32 + i) * 64;
+        rb = (wn * 32 + i) * 64;
+    }
+
+    // source chunk (in halves) for staging lane l
+    static __device__ __forceinline__ int stage_row(int w, int l, int j) { return (w + 8 * j) * 8 + (l >> 3); }
+    static __device__ __forceinline__ int stage_chunk(int row, int l) { return ((l & 7) ^ ((row >> 1) & 7)) * 8; }
+
+    template <int TYPE>
+    __device__ __forceinline__ void stage(int t) {
+        _Float16 *dst = smem + (t & 1) * PIPE_BUF_HALVES + TYPE * PIPE_HALF_HALVES + w * 512;
+        if (DBG && (dbg & 8)) return;            // ablation: stage nothing (prologue included)
+        int k0 = t * 64;
+        if (DBG && (dbg & 1)) k0 = (t & 1) * 64;  // ablation: re-read the first two K-tiles (always cache hits)
+        __builtin_amdgcn_global_load_lds((pipe_glb_t *)(src[TYPE][0] + k0), (pipe_lds_t *)dst, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((pipe_glb_t *)(src[TYPE][1] + k0), (pipe_lds_t *)(dst + 8 * 512), 16, 0, 0);
+    }
+    template <int H>
+    __device__ __forceinline__ void read_a(int t) {
+        const _Float16 *base = smem + (t & 1) * PIPE_BUF_HALVES + H * PIPE_HALF_HALVES;
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int yy = 0; yy < 2; ++yy) fa[yy][s] = *reinterpret_cast<const f16x8 *>(base + ra[yy] + kx[s]);
+    }
+    template <int H>
+    __device__ __forceinline__ void read_b(int t) {
+        const _Float16 *base = smem + (t & 1) * PIPE_BUF_HALVES + (2 + H) * PIPE_HALF_HALVES;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) fb[H][s] = *reinterpret_cast<const f16x8 *>(base + rb + kx[s]);
+    }
+    template <int X, int YH>
+    __device__ __forceinline__ void mfma(f32x16 (&acc)[2][4]) {
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+        if (DBG && (dbg & 2)) {  // ablation: keep the LDS reads alive, skip the matrix pipe
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                asm volatile("" ::"v"(fb[X][s]));
+#pragma unroll
+                for (int yy = 0; yy < 2; ++yy) asm volatile("" ::"v"(fa[yy][s]));
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int yy = 0; yy < 2; ++yy)
+                    acc[X][2 * YH + yy] =
+                        __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[X][s], fa[yy][s], acc[X][2 * YH + yy], 0, 0, 0);
+        }
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    }
+
+    // MODE 0: steady state (tiles t+1, t+2 exist); 1: t = NK-2; 2: t = NK-1
+    template <int MODE>
+    __device__ __forceinline__ void tile(int t, f32x16 (&acc)[2][4]) {
+        // c0
+        read_a<0>(t);
+        read_b<0>(t);
+        if constexpr (MODE <= 1) { stage<3>(t + 1); PIPE_WAIT_VM(8); } else { PIPE_WAIT_VM(2); }
+        mfma<0, 0>(acc);
+        // c1
+        read_b<1>(t);
+        if constexpr (MODE <= 1) { stage<1>(t + 1); PIPE_WAIT_VM(8); } else { PIPE_WAIT_VM(0); }
+        mfma<1, 0>(acc);
+        // c2
+        read_a<1>(t);
+        if constexpr (MODE == 0) { stage<0>(t + 2); PIPE_WAIT_VM(8); }
+        mfma<1, 1>(acc);
+        // c3
+        if constexpr (MODE == 0) { stage<2>(t + 2); PIPE_WAIT_VM(8); }
+        if constexpr (MODE == 1) { PIPE_WAIT_VM(4); }
+        mfma<0, 1>(acc);
+    }
+
+    // Whole K loop of one output tile.  All 512 threads; on return every wave has passed the same
+    // number of barriers and no LDS-DMA is in flight.
+    __device__ __forceinline__ void run(int NK, f32x16 (&acc)[2][4]) {
+        stage<0>(0); stage<2>(0); stage<3>(0); stage<1>(0); stage<0>(1); stage<2>(1);
+        PIPE_WAIT_VM(8);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        if (w >= 4) __builtin_amdgcn_s_barrier();  // wm = 1 runs one barrier behind
+        __builtin_amdgcn_sched_barrier(0);
+        for (int t = 0; t < NK - 2; ++t) tile<0>(t, acc);
+        tile<1>(NK - 2, acc);
+        tile<2>(NK - 1, acc);
+        if (w < 4) __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    }
+};
+using Pipe256 = Pipe256T<false>;
+
+}  // namespace ance

@@ -1,18 +1,22 @@
 """Host-side stages around the search: query chunking, dev NDCG@10, hard-negative selection and
 the ``ann_training_data_N`` / ``ann_ndcg_N`` writers (the file contract, seam B1).
 
-Same behaviour as the reference functions they stand in for -- cited per function -- but written
-over NumPy arrays instead of per-element Python lookups.  Randomness goes through the module-level
-``random`` exactly where the reference consumes it (one ``random.shuffle`` of ``range(k)`` per
-query in row order, then one shuffle of the query order), so a run is reproducible under
-``random.seed`` and comparable with a seeded reference run.
+Same behaviour as the reference functions they stand in for -- cited per function.  The O(nq k)
+negative selection and the training-file writer run in the native host stage of libance_amd.so
+(csrc/host_postsearch.hip) instead of per-element Python.  Randomness is drawn
+from the module-level ``random`` stream exactly where the reference consumes it (one
+``random.shuffle`` of ``range(k)`` per query in row order, then one shuffle of the query order):
+the native code continues CPython's Mersenne Twister state in place, so a run is reproducible
+under ``random.seed`` and byte-comparable with a seeded reference run.
 """
+import ctypes
 import json
-import math
 import os
 import random
 
 import numpy as np
+
+from . import _lib
 
 
 def query_chunk(num_queries, output_num, chunk_factor):
@@ -71,67 +75,141 @@ def eval_dev_query(query_embedding2id, passage_embedding2id, dev_query_positive_
     return (total / cnt if cnt else 0.0), cnt
 
 
+class NegativeSelection:
+    """Row-wise result of the negative selection: ``neg`` int64 [nq, negative_sample] (-1 padded),
+    ``cnt`` int32 [nq] (-1 for rows whose query is not effective), ``pos_pid`` int64 [nq] (-1 when the
+    query has no positive), ``mrr`` (the reference's accumulator / num_queries)."""
+
+    def __init__(self, q2id, pos_pid, active, neg, cnt, mrr, num_queries):
+        self.q2id, self.pos_pid, self.active, self.neg, self.cnt = q2id, pos_pid, active, neg, cnt
+        self.mrr, self.num_queries = mrr, num_queries
+
+    def as_dict(self):
+        """{qid: [negative pid, ...]} -- a repeated query id keeps its last row, like the reference's dict."""
+        out = {}
+        rows = np.nonzero(self.active)[0]
+        negs = self.neg[rows].tolist()
+        for qid, c, lst in zip(self.q2id[rows].tolist(), self.cnt[rows].tolist(), negs):
+            out[qid] = lst[:c]
+        return out
+
+
+def _mt_state():
+    st = random.getstate()
+    if st[0] != 3 or len(st[1]) != 625:
+        raise RuntimeError("unexpected random.getstate() layout")
+    return st, np.array(st[1], dtype=np.uint32)
+
+
+def _mt_install(st, words):
+    random.setstate((st[0], tuple(words.tolist()), st[2]))
+
+
+def _ptr(a):
+    return ctypes.c_void_p(a.ctypes.data)
+
+
+def py_shuffled_range(n):
+    """``x = list(range(n)); random.shuffle(x)`` as an int64 array, drawn natively from (and advancing)
+    the module-level ``random`` state."""
+    st, words = _mt_state()
+    out = np.empty(int(n), dtype=np.int64)
+    _lib.check(_lib.lib().ance_host_py_shuffle(_ptr(words), int(n), _ptr(out)), "ance_host_py_shuffle")
+    _mt_install(st, words)
+    return out
+
+
+def select_negatives(query_embedding2id, passage_embedding2id, training_query_positive_id, I, effective_q_id,
+                     negative_sample, select_topk, n_threads=0):
+    """Hard-negative selection of drivers/run_ann_data_gen.py:339-396 through the native host stage
+    ``ance_host_select_negatives`` (include/ance_amd.h).
+
+    Per query row whose id is in ``effective_q_id``: candidates = the k neighbours in a
+    ``random.shuffle``d order (default) or the first ``negative_sample + 1`` in rank order
+    (``--ann_measure_topk_mrr``); walk them, skip the positive (adding 1/rank to the MRR if
+    rank <= 10), skip repeated pids, stop at ``negative_sample`` negatives.  The shuffles consume the
+    module-level ``random`` stream exactly as the reference does."""
+    I = np.ascontiguousarray(np.asarray(I), dtype=np.int64)
+    p2id = np.ascontiguousarray(np.asarray(passage_embedding2id).reshape(-1), dtype=np.int64)
+    q2id = np.ascontiguousarray(np.asarray(query_embedding2id).reshape(-1), dtype=np.int64)
+    nq, k = I.shape
+    qlist = q2id[:nq].tolist()
+    active = np.fromiter((q in effective_q_id for q in qlist), dtype=np.uint8, count=nq)
+    get = training_query_positive_id.get
+    pos_l = [get(q, -1) for q in qlist]
+    pos_pid = np.asarray(pos_l, dtype=np.int64) if nq else np.zeros(0, np.int64)
+    missing = np.nonzero((active != 0) & (pos_pid < 0))[0]
+    for r in missing.tolist():
+        if qlist[r] not in training_query_positive_id:
+            raise KeyError(qlist[r])  # the reference indexes the dict for every effective query
+    neg = np.empty((nq, negative_sample), dtype=np.int64)
+    cnt = np.empty(nq, dtype=np.int32)
+    mrr = ctypes.c_double(0.0)
+    st, words = _mt_state()
+    rc = _lib.lib().ance_host_select_negatives(_ptr(words), _ptr(I), nq, k, _ptr(p2id), p2id.shape[0], _ptr(pos_pid),
+                                               _ptr(active), int(negative_sample), 1 if select_topk else 0,
+                                               int(n_threads), _ptr(neg), _ptr(cnt), ctypes.byref(mrr))
+    _lib.check(rc, "ance_host_select_negatives")
+    if not select_topk:
+        _mt_install(st, words)
+    num_queries = int(active.sum())
+    return NegativeSelection(q2id[:nq], pos_pid, active, neg, cnt, mrr.value / max(num_queries, 1), num_queries)
+
+
 def generate_negative_passage_ids(query_embedding2id, passage_embedding2id, training_query_positive_id, I,
                                   effective_q_id, negative_sample, select_topk, rank=0, verbose=True):
-    """{qid: [negative pid, ...]} (drivers/run_ann_data_gen.py:339-396).
-
-    Per query row: candidates = the k neighbours in a ``random.shuffle``d order (default) or the
-    first ``negative_sample + 1`` in rank order (``--ann_measure_topk_mrr``); walk them, skip the
-    positive (adding 1/rank to the MRR if rank <= 10), skip repeated pids, stop at
-    ``negative_sample`` negatives."""
-    I = np.asarray(I)
-    p2id = np.asarray(passage_embedding2id)
-    q2id = np.asarray(query_embedding2id).tolist()
-    k = I.shape[1]
-    out = {}
-    mrr = 0.0
-    num_queries = 0
-    base_order = list(range(k))
-    for row, qid in enumerate(q2id):
-        if qid not in effective_q_id:
-            continue
-        num_queries += 1
-        pos_pid = training_query_positive_id[qid]
-        if select_topk:
-            sel = I[row, :negative_sample + 1]
-        else:
-            order = base_order[:]
-            random.shuffle(order)
-            sel = I[row, order]
-        pids = p2id[sel]
-        is_pos = pids == pos_pid
-        if select_topk and is_pos[:10].any():
-            mrr += float((1.0 / (np.nonzero(is_pos[:10])[0] + 1)).sum())
-        cand = pids[~is_pos]
-        if cand.size:
-            _, first = np.unique(cand, return_index=True)
-            first.sort()
-            negs = cand[first[:negative_sample]]
-        else:
-            negs = cand
-        out[qid] = negs.tolist()
+    """{qid: [negative pid, ...]} (drivers/run_ann_data_gen.py:339-396); see ``select_negatives``."""
+    sel = select_negatives(query_embedding2id, passage_embedding2id, training_query_positive_id, I, effective_q_id,
+                           negative_sample, select_topk)
     if select_topk and verbose:
-        print("Rank:" + str(rank) + " --- ANN MRR:" + str(mrr / max(num_queries, 1)))
-    return out
+        print("Rank:" + str(rank) + " --- ANN MRR:" + str(sel.mrr))
+    return sel.as_dict()
 
 
 def write_ann_files(output_dir, output_num, n_rows, query_embedding2id, effective_q_id, training_query_positive_id,
                     query_negative_passage, dev_ndcg, checkpoint_path, extra_metrics=None):
     """``ann_training_data_N`` then ``ann_ndcg_N`` -- data file first, the trainer discovers a
     refresh by the ndcg file (drivers/run_ann_data_gen.py:314-334; utils/util.py:229-243).
-    Lines: ``qid \\t pos_pid \\t neg,neg,...`` in a ``random.shuffle``d query order."""
-    q2id = np.asarray(query_embedding2id).tolist()
+    Lines: ``qid \\t pos_pid \\t neg,neg,...`` in a ``random.shuffle``d query order.
+    ``query_negative_passage``: a ``NegativeSelection`` or the reference's {qid: [pid, ...]} dict."""
+    q2id = np.ascontiguousarray(np.asarray(query_embedding2id).reshape(-1)[:n_rows], dtype=np.int64)
+    qlist = q2id.tolist()
+    get = training_query_positive_id.get
+    if isinstance(query_negative_passage, NegativeSelection):
+        sel = query_negative_passage
+        neg, cnt, pos_pid = sel.neg, sel.cnt, sel.pos_pid
+        writable = (sel.active != 0) & np.fromiter((q in training_query_positive_id for q in qlist), dtype=bool,
+                                                   count=n_rows)
+        # negatives are keyed by query id in the reference: a repeated id prints its last row's list
+        uq, inv = np.unique(q2id, return_inverse=True)
+        last = np.full(uq.shape[0], -1, dtype=np.int64)
+        act_rows = np.nonzero(sel.active)[0]
+        np.maximum.at(last, inv[act_rows], act_rows)
+        src_row = np.where(writable, last[inv], -1).astype(np.int64)
+    else:
+        lists = [query_negative_passage[q] if (q in effective_q_id and q in training_query_positive_id) else None
+                 for q in qlist]
+        width = max([len(x) for x in lists if x is not None] + [0])
+        neg = np.full((n_rows, width), -1, dtype=np.int64)
+        cnt = np.zeros(n_rows, dtype=np.int32)
+        for r, x in enumerate(lists):
+            if x is not None:
+                cnt[r] = len(x)
+                neg[r, :len(x)] = x
+        pos_pid = np.asarray([get(q, -1) for q in qlist], dtype=np.int64) if n_rows else np.zeros(0, np.int64)
+        src_row = np.asarray([r if x is not None else -1 for r, x in enumerate(lists)], dtype=np.int64)
+    neg = np.ascontiguousarray(neg, dtype=np.int64)
+    cnt = np.ascontiguousarray(cnt, dtype=np.int32)
+    pos_pid = np.ascontiguousarray(pos_pid, dtype=np.int64)
+    src_row = np.ascontiguousarray(src_row, dtype=np.int64)
+    order = py_shuffled_range(n_rows)
     train_path = os.path.join(output_dir, "ann_training_data_" + str(output_num))
     tmp = train_path + ".tmp"
-    with open(tmp, "w") as f:
-        query_range = list(range(n_rows))
-        random.shuffle(query_range)
-        for query_idx in query_range:
-            qid = q2id[query_idx]
-            if qid not in effective_q_id or qid not in training_query_positive_id:
-                continue
-            f.write("{}\t{}\t{}\n".format(qid, training_query_positive_id[qid],
-                                          ",".join(str(p) for p in query_negative_passage[qid])))
+    lines = ctypes.c_int64(0)
+    rc = _lib.lib().ance_host_write_ann_training(tmp.encode(), _ptr(order), n_rows, _ptr(q2id), _ptr(pos_pid),
+                                                 _ptr(src_row), _ptr(neg), _ptr(cnt), int(neg.shape[1]),
+                                                 ctypes.byref(lines))
+    _lib.check(rc, "ance_host_write_ann_training")
     os.replace(tmp, train_path)
     payload = {"ndcg": dev_ndcg, "checkpoint": checkpoint_path}
     if extra_metrics:

@@ -166,9 +166,12 @@ int ance_encode_ids(AnceEncoder *enc, const int32_t *d_ids, int64_t ld_ids, cons
 /*
  * Test / measurement hook: C = A . B^T (+ epilogue) with the encoder's GEMM kernel on caller data.
  *   epi 0: out f16 = acc + bias[n]; 1: out f16 = gelu(acc + bias[n]); 2: out f32 = acc + bias[n] + res32
- *   d_a_f16 [M,K], d_b_f16 [N,K] fp16 row-major; M, N multiples of 256, K of 64.
- *   ablate 0: the product kernel.  Bits select a measurement ablation (results are then WRONG on
- *   purpose): 1 = no global loads after the first K-tile, 2 = no MFMA, 4 = every block loads tile (0,0).
+ *   d_a_f16 [M,K], d_b_f16 [N,K] fp16 row-major; M, N multiples of 256, K a multiple of 64, >= 128.
+ *   ablate 0: the product kernel (ping-pong main loop).  Non-zero selects the two-phase loop it
+ *   replaced, with measurement ablations by bit (results are then WRONG on purpose): 1 = no global
+ *   loads after the first K-tile, 2 = no MFMA, 4 = every block loads tile (0,0); 8 = no ablation
+ *   (correct results; the A/B reference for the main loop).  16 + bits: the ping-pong loop with
+ *   ablations 1 = every K-tile re-reads tiles 0/1, 2 = no MFMA, 4 = tile (0,0), 8 = no staging at all.
  */
 int ance_debug_gemm(int ablate, int epi, const void *d_a_f16, const void *d_b_f16, int M, int N, int K,
                     const float *d_bias, void *d_out, const float *d_res32, void *stream);
@@ -177,6 +180,43 @@ int ance_debug_gemm(int ablate, int epi, const void *d_a_f16, const void *d_b_f1
  * known without a sync, so the library exposes the pure function instead:
  * F_enc(T) = 169,869,312 T + 36,864 T^2 + 1,179,648 per sequence of T tokens. */
 double ance_encoder_flops_per_sequence(int T);
+
+/* ---------------------------------------------------------------------------------------------
+ * Host-side post-search stage.  Pure host code, HOST pointers, no GPU work:
+ * replaces the per-element Python of GenerateNegativePassaageID
+ * (drivers/run_ann_data_gen.py:339-396) and of the ann_training_data_N writer (:314-327).
+ *
+ * mt_state: uint32[625] = CPython `random.getstate()[1]` (624 Mersenne-Twister words + index).
+ * The functions draw exactly what the reference's `random.shuffle` calls would draw and leave the
+ * advanced state in place (install it with `random.setstate`), so a seeded run produces the
+ * reference's files byte for byte.
+ * ------------------------------------------------------------------------------------------- */
+
+/* out[0..n) = list(range(n)) after random.shuffle (the line order of ann_training_data_N, :316-317). */
+int ance_host_py_shuffle(uint32_t *mt_state, int64_t n, int64_t *out);
+
+/*
+ * Negative selection for every query row r with active[r] != 0 (query id in effective_q_id):
+ * candidates = I[r, order] with order = random.shuffle(range(k)) (select_topk == 0; one shuffle per
+ * active row, row order) or I[r, :negative_sample+1] (select_topk != 0, --ann_measure_topk_mrr);
+ * walk them as the reference does: pid = p2id[row] (negative row ids index from the end like
+ * NumPy), skip pid == pos_pid[r] (rank <= 10 adds 1/rank to *out_mrr), skip pids already taken,
+ * stop at negative_sample.  out_neg [nq, negative_sample] (-1 padded), out_cnt [nq] (-1 for
+ * inactive rows).  *out_mrr = the reference's `mrr` accumulator (before the division), summed in
+ * its order.  n_threads <= 0: up to 16.  mt_state may be NULL when select_topk != 0.
+ */
+int ance_host_select_negatives(uint32_t *mt_state, const int64_t *I, int64_t nq, int k, const int64_t *p2id,
+                               int64_t n_rows, const int64_t *pos_pid, const uint8_t *active, int negative_sample,
+                               int select_topk, int n_threads, int64_t *out_neg, int32_t *out_cnt, double *out_mrr);
+
+/*
+ * Writes "qid \t pos_pid \t neg,neg,...\n" for rows order[0..n_order) whose src_row[row] >= 0, taking
+ * the negatives of row src_row[row] (the reference keys them by query id, so a repeated id shows
+ * the negatives of its last row).  *out_lines = lines written.
+ */
+int ance_host_write_ann_training(const char *path, const int64_t *order, int64_t n_order, const int64_t *qid,
+                                 const int64_t *pos_pid, const int64_t *src_row, const int64_t *neg, const int32_t *cnt,
+                                 int negative_sample, int64_t *out_lines);
 
 #ifdef __cplusplus
 }

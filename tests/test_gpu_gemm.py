@@ -32,7 +32,7 @@ def _run(epi, M, N, K, seed=0):
 
 
 @pytest.mark.parametrize("epi", [0, 1, 2])
-@pytest.mark.parametrize("shape", [(256, 256, 64), (512, 768, 768), (768, 256, 3072), (1024, 3072, 128), (2304, 1536, 768)])
+@pytest.mark.parametrize("shape", [(256, 256, 128), (512, 768, 768), (768, 256, 3072), (1024, 3072, 128), (2304, 1536, 768)])
 def test_gemm_matches_fp32_reference(epi, shape):
     M, N, K = shape
     out, ref = _run(epi, M, N, K, seed=epi)
@@ -51,4 +51,5 @@ def test_bad_shapes_are_rejected():
     t = torch.zeros(16, device="cuda")
     p = ctypes.c_void_p(t.data_ptr())
     assert L.ance_debug_gemm(0, 0, p, p, 128, 256, 64, p, p, None, _lib.current_stream_ptr()) == -1
-    assert L.ance_debug_gemm(0, 5, p, p, 256, 256, 64, p, p, None, _lib.current_stream_ptr()) == -1
+    assert L.ance_debug_gemm(0, 5, p, p, 256, 256, 128, p, p, None, _lib.current_stream_ptr()) == -1
+    assert L.ance_debug_gemm(0, 0, p, p, 256, 256, 64, p, p, None, _lib.current_stream_ptr()) == -1  # needs >= 2 K-tiles

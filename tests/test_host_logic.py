@@ -161,3 +161,82 @@ def test_cli_flags_match_reference_names():
     assert (a.topk_training, a.negative_sample, a.end_output_num, a.ann_chunk_factor) == (200, 20, 0, 5)
     assert a.max_seq_length == 128 and a.max_query_length == 64 and a.per_gpu_eval_batch_size == 128
     assert a.ann_measure_topk_mrr and a.inference and a.local_rank == 3 and not a.only_keep_latest_embedding_file
+
+
+# ---- native host stage (csrc/host_postsearch.hip) ------------------------------------------------
+def test_native_shuffle_continues_cpython_stream():
+    for n in (0, 1, 2, 3, 7, 200, 1000, 4097, 100003):
+        random.seed(1000 + n)
+        random.random()  # move the index off the seed position
+        st = random.getstate()
+        ref = list(range(n))
+        random.shuffle(ref)
+        after_ref = random.getstate()
+        random.setstate(st)
+        got = negatives.py_shuffled_range(n)
+        assert got.tolist() == ref
+        assert random.getstate() == after_ref  # the very next draw of a caller is unchanged too
+
+
+def _random_case(rng, nq, k, n_rows, chunks, dup_q=False, with_pad=False, inactive=False):
+    p2id = (np.arange(n_rows) // chunks).astype(np.int64)
+    q2id = np.arange(1000, 1000 + nq, dtype=np.int64)
+    if dup_q:
+        q2id[nq // 2] = q2id[3]
+        q2id[nq - 1] = q2id[3]
+    I = rng.integers(0, n_rows, size=(nq, k)).astype(np.int64)
+    if with_pad:
+        I[::7, -3:] = -1
+    pos = {int(q): int(p2id[I[r, int(rng.integers(0, min(k, 12)))]]) for r, q in enumerate(q2id.tolist())}
+    eff = set(q2id.tolist())
+    if inactive:
+        eff = set(q2id[::3].tolist())
+    return q2id, p2id, pos, I, eff
+
+
+@pytest.mark.parametrize("nq,k,chunks,flags", [(50, 20, 1, {}), (300, 64, 4, dict(dup_q=True)),
+                                               (5000, 40, 1, dict(with_pad=True, inactive=True)),
+                                               (4500, 200, 4, dict(dup_q=True, inactive=True))])
+def test_native_selection_and_writer_match_oracle(tmp_path, nq, k, chunks, flags):
+    rng = np.random.default_rng(nq + k)
+    q2id, p2id, pos, I, eff = _random_case(rng, nq, k, 3000, chunks, **flags)
+    for topk in (False, True):
+        for ns in (0, 1, 7):
+            random.seed(77)
+            sel = negatives.select_negatives(q2id, p2id, pos, I, eff, ns, topk)
+            a = sel.as_dict()
+            d1 = tmp_path / ("a%d%d" % (topk, ns))
+            d1.mkdir()
+            negatives.write_ann_files(str(d1), 1, nq, q2id, eff, pos, sel, 0.5, "/m/checkpoint-7/")
+            s1 = random.getstate()
+            random.seed(77)
+            b, mrr = ann_ref.generate_negative_passage_ids(q2id, p2id, pos, I, eff, ns, topk)
+            d2 = tmp_path / ("b%d%d" % (topk, ns))
+            d2.mkdir()
+            ann_ref.write_ann_files(str(d2), 1, I, q2id, eff, pos, b, 0.5, "/m/checkpoint-7/")
+            assert a == b
+            assert mrr is None or sel.mrr == mrr
+            assert (d1 / "ann_training_data_1").read_text() == (d2 / "ann_training_data_1").read_text()
+            assert random.getstate() == s1
+            # dict input goes through the same writer
+            random.seed(5)
+            d3 = tmp_path / ("c%d%d" % (topk, ns))
+            d3.mkdir()
+            negatives.write_ann_files(str(d3), 1, nq, q2id, eff, pos, a, 0.5, "/m/checkpoint-7/")
+            random.seed(5)
+            d4 = tmp_path / ("d%d%d" % (topk, ns))
+            d4.mkdir()
+            ann_ref.write_ann_files(str(d4), 1, I, q2id, eff, pos, b, 0.5, "/m/checkpoint-7/")
+            assert (d3 / "ann_training_data_1").read_text() == (d4 / "ann_training_data_1").read_text()
+
+
+def test_native_selection_errors():
+    rng = np.random.default_rng(3)
+    q2id, p2id, pos, I, eff = _random_case(rng, 20, 10, 100, 1)
+    del pos[int(q2id[4])]
+    with pytest.raises(KeyError):
+        negatives.select_negatives(q2id, p2id, pos, I, eff, 3, False)
+    q2id, p2id, pos, I, eff = _random_case(rng, 20, 10, 100, 1)
+    I[2, 2] = 100  # out of range row id
+    with pytest.raises(Exception):
+        negatives.select_negatives(q2id, p2id, pos, I, eff, 3, False)
