@@ -9,24 +9,27 @@
 // blocks {h, h+2, h+4, h+6} of the B tile (x = h).  A K-tile is consumed in four phases, one
 // 64 x 32 output quadrant of every wave each:
 //
-//   phase c0: read A-half0 + B-half0   MFMA acc[0][0..1]      stage B-half1 of tile t+1
-//   phase c1: read B-half1             MFMA acc[1][0..1]      stage A-half1 of tile t+1
-//   phase c2: read A-half1             MFMA acc[1][2..3]      stage A-half0 of tile t+2
-//   phase c3: (B-half0 kept in VGPRs)  MFMA acc[0][2..3]      stage B-half0 of tile t+2
+//   phase c0: read A-half0 + B-half0   MFMA acc[0][0..1]  + stage B-half1 of tile t+1
+//   phase c1: read B-half1             MFMA acc[1][0..1]  + stage A-half1 of tile t+1
+//   phase c2: read A-half1             MFMA acc[1][2..3]  + stage A-half0 of tile t+2
+//   phase c3: (B-half0 kept in VGPRs)  MFMA acc[0][2..3]  + stage B-half0 of tile t+2
 //
-// Every phase is  { ds_reads ; 2 x global_load_lds ; s_waitcnt vmcnt(8) }  s_barrier  { 8 MFMA }
-// s_barrier.  The four waves with wm = 1 run one barrier behind the four with wm = 0, so on every
-// SIMD one wave is in its MFMA half-phase while the other one reads LDS and issues loads: the
-// matrix pipe never waits for a ds_read, and staged half-tiles stay in flight across barriers
-// (5-6 phases ahead, counted vmcnt, never 0 in steady state).
+// Every phase is  { ds_reads ; s_waitcnt vmcnt(6) }  s_barrier  { 8 MFMA with 2 global_load_lds
+// issued between them }  s_barrier.  The four waves with wm = 1 run one barrier behind the four
+// with wm = 0, so on every SIMD one wave is in its MFMA half-phase while the other one reads LDS:
+// the matrix pipe never waits for a ds_read, and staged half-tiles stay in flight across barriers
+// (5-6 phases ahead, counted vmcnt, never 0 in steady state).  The LDS-DMAs sit in the MFMA
+// half-phase because their issue cost (60-185 cycles each beside ds_reads) does not fit in the read
+// half-phase; measured on 8192^3: 935 -> see DESIGN.md.
 //
-// Hazards (slot = interval between two barriers; wm=0 reads in slot 2p, wm=1 in slot 2p+1):
+// Hazards (slot = interval between two barriers; wm=0 reads in slot 2p and computes in slot 2p+1,
+// wm=1 one slot later):
 //   RAW  a half-tile read in phase p was staged in phase p-5 (or p-6); every wave retires its own
-//        pieces with vmcnt(8) at the end of its read half-phase p-1, i.e. before the barrier that
-//        precedes the first read.
+//        pieces with vmcnt(6) at the end of its read half-phase p-1 (three younger half-tiles may stay
+//        in flight), i.e. before the barrier that precedes the first read.
 //   WAR  a half-tile read in phase p is restaged in phase p+2 at the earliest: the last ds_read of
 //        it (wm=1, slot 2p+1) has returned before that wave's MFMAs of slot 2p+2 finish (they consume
-//        it), and the barrier ending slot 2p+2 precedes the first restage (wm=0, slot 2p+4).
+//        it), and the barrier ending slot 2p+2 precedes the first restage (wm=0, slot 2p+5).
 // Needs NK >= 2 K-tiles.  The last two tiles are peeled (nothing left to stage, smaller counts).
 #pragma once
 #include "common.h"
@@ -76,14 +79,18 @@ struct Pipe256T {
     static __device__ __forceinline__ int stage_row(int w, int l, int j) { return (w + 8 * j) * 8 + (l >> 3); }
     static __device__ __forceinline__ int stage_chunk(int row, int l) { return ((l & 7) ^ ((row >> 1) & 7)) * 8; }
 
-    template <int TYPE>
-    __device__ __forceinline__ void stage(int t) {
-        _Float16 *dst = smem + (t & 1) * PIPE_BUF_HALVES + TYPE * PIPE_HALF_HALVES + w * 512;
+    template <int TYPE, int J>
+    __device__ __forceinline__ void stage_piece(int t) {
         if (DBG && (dbg & 8)) return;            // ablation: stage nothing (prologue included)
+        _Float16 *dst = smem + (t & 1) * PIPE_BUF_HALVES + TYPE * PIPE_HALF_HALVES + (w + 8 * J) * 512;
         int k0 = t * 64;
         if (DBG && (dbg & 1)) k0 = (t & 1) * 64;  // ablation: re-read the first two K-tiles (always cache hits)
-        __builtin_amdgcn_global_load_lds((pipe_glb_t *)(src[TYPE][0] + k0), (pipe_lds_t *)dst, 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((pipe_glb_t *)(src[TYPE][1] + k0), (pipe_lds_t *)(dst + 8 * 512), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((pipe_glb_t *)(src[TYPE][J] + k0), (pipe_lds_t *)dst, 16, 0, 0);
+    }
+    template <int TYPE>
+    __device__ __forceinline__ void stage(int t) {
+        stage_piece<TYPE, 0>(t);
+        stage_piece<TYPE, 1>(t);
     }
     template <int H>
     __device__ __forceinline__ void read_a(int t) {
@@ -99,26 +106,34 @@ struct Pipe256T {
 #pragma unroll
         for (int s = 0; s < 4; ++s) fb[H][s] = *reinterpret_cast<const f16x8 *>(base + rb + kx[s]);
     }
-    template <int X, int YH>
-    __device__ __forceinline__ void mfma(f32x16 (&acc)[2][4]) {
+    // MFMA half-phase: barrier, 8 MFMAs with the two LDS-DMA pieces of half-tile STAGE (of K-tile ts)
+    // issued in the shadow of the matrix pipe (an LDS-DMA costs 60-185 issue cycles in a read
+    // half-phase, which is the one with no slack), barrier.  STAGE < 0: nothing to stage.
+    template <int X, int YH, int STAGE>
+    __device__ __forceinline__ void mfma(f32x16 (&acc)[2][4], int ts) {
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_setprio(1);
-        if (DBG && (dbg & 2)) {  // ablation: keep the LDS reads alive, skip the matrix pipe
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                asm volatile("" ::"v"(fb[X][s]));
+        for (int s = 0; s < 4; ++s) {
 #pragma unroll
-                for (int yy = 0; yy < 2; ++yy) asm volatile("" ::"v"(fa[yy][s]));
-            }
-        } else {
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
-#pragma unroll
-                for (int yy = 0; yy < 2; ++yy)
+            for (int yy = 0; yy < 2; ++yy) {
+                if (DBG && (dbg & 2)) {  // ablation: keep the LDS reads alive, skip the matrix pipe
+                    asm volatile("" ::"v"(fb[X][s]), "v"(fa[yy][s]));
+                } else {
                     acc[X][2 * YH + yy] =
                         __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[X][s], fa[yy][s], acc[X][2 * YH + yy], 0, 0, 0);
+                }
+            }
+            if constexpr (STAGE >= 0) {
+                if (s == 0 || s == 2) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (s == 0) stage_piece<(STAGE >= 0 ? STAGE : 0), 0>(ts);
+                    else stage_piece<(STAGE >= 0 ? STAGE : 0), 1>(ts);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
         }
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
@@ -129,23 +144,22 @@ struct Pipe256T {
     // MODE 0: steady state (tiles t+1, t+2 exist); 1: t = NK-2; 2: t = NK-1
     template <int MODE>
     __device__ __forceinline__ void tile(int t, f32x16 (&acc)[2][4]) {
-        // c0
+        // c0 (the wait at the end of each read half-phase retires what the NEXT phase reads)
         read_a<0>(t);
         read_b<0>(t);
-        if constexpr (MODE <= 1) { stage<3>(t + 1); PIPE_WAIT_VM(8); } else { PIPE_WAIT_VM(2); }
-        mfma<0, 0>(acc);
+        if constexpr (MODE <= 1) PIPE_WAIT_VM(6); else PIPE_WAIT_VM(2);
+        mfma<0, 0, (MODE <= 1 ? 3 : -1)>(acc, t + 1);
         // c1
         read_b<1>(t);
-        if constexpr (MODE <= 1) { stage<1>(t + 1); PIPE_WAIT_VM(8); } else { PIPE_WAIT_VM(0); }
-        mfma<1, 0>(acc);
+        if constexpr (MODE <= 1) PIPE_WAIT_VM(6); else PIPE_WAIT_VM(0);
+        mfma<1, 0, (MODE <= 1 ? 1 : -1)>(acc, t + 1);
         // c2
         read_a<1>(t);
-        if constexpr (MODE == 0) { stage<0>(t + 2); PIPE_WAIT_VM(8); }
-        mfma<1, 1>(acc);
+        mfma<1, 1, (MODE == 0 ? 0 : -1)>(acc, t + 2);
         // c3
-        if constexpr (MODE == 0) { stage<2>(t + 2); PIPE_WAIT_VM(8); }
-        if constexpr (MODE == 1) { PIPE_WAIT_VM(4); }
-        mfma<0, 1>(acc);
+        if constexpr (MODE == 0) PIPE_WAIT_VM(6);
+        if constexpr (MODE == 1) PIPE_WAIT_VM(4);
+        mfma<0, 1, (MODE == 0 ? 2 : -1)>(acc, t + 2);
     }
 
     // Whole K loop of one output tile.  All 512 threads; on return every wave has passed the same
