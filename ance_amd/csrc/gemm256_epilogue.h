@@ -9,20 +9,26 @@
 
 namespace ance {
 
-// GELU(x) = x * Phi(x) with Phi from the Abramowitz-Stegun 7.1.26 erfc polynomial (|abs err| of
-// erf <= 1.5e-7, far below the fp16 resolution of the stored result): ~14 VALU ops instead of the
-// ~30 of ocml's erff, which matters because this epilogue runs on 3072 columns per token with no
-// MFMA work to hide behind.  The erfc form keeps the negative tail free of cancellation.
-__device__ __forceinline__ float gelu_erf256(float x) {
-    const float z = x * 0.70710678118654752440f;
-    const float az = fabsf(z);
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, az, 1.0f));
-    float p = fmaf(t, 1.061405429f, -1.453152027f);
-    p = fmaf(t, p, 1.421413741f);
-    p = fmaf(t, p, -0.284496736f);
-    p = fmaf(t, p, 0.254829592f);
-    const float h = 0.5f * p * t * __expf(-az * az);  // 0.5 * erfc(|z|)
-    return x * (z >= 0.0f ? 1.0f - h : h);
+// GELU(x) = x * Phi(x) = max(x, 0) - |x| * h(|x| / sqrt 2),  h(z) = erfc(z) / 2 = 2^q(z).
+// q is a degree-5 least-squares fit of log2(erfc(z) / 2) on [0, 5] weighted by z h(z) (the factor
+// the error is multiplied with); beyond 5 q keeps falling, so h underflows to 0 as it should.
+// |GELU error| <= 8e-6 over [-9, 9] in fp32 (the stored result is fp16: 2^-11 relative), checked
+// against scipy's erf when the coefficients were fitted.  One transcendental (v_exp_f32) and, on four
+// adjacent columns at a time, 8 packed-fp32 ops per pair -- the A-S 7.1.26 rational form this
+// replaces needed v_rcp + v_exp + 17 scalar ops per element, and this epilogue runs on 3072 columns
+// per token with no MFMA work to hide behind (one workgroup per CU).
+__device__ __forceinline__ f32x4 gelu_erf256(f32x4 x) {
+    const f32x4 ax = __builtin_elementwise_abs(x);
+    const f32x4 z = ax * 0.70710678118654752440f;
+    f32x4 q = z * -0.00133047544f + 0.0201726463f;
+    q = q * z + -0.129834279f;
+    q = q * z + -0.934321642f;
+    q = q * z + -1.62252474f;
+    q = q * z + -1.00054646f;
+    f32x4 h;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) h[e] = __builtin_amdgcn_exp2f(q[e]);
+    return __builtin_elementwise_max(x, f32x4{0.0f, 0.0f, 0.0f, 0.0f}) - ax * h;
 }
 
 template <int EPI>
@@ -116,14 +122,14 @@ __device__ __forceinline__ void gemm256_epilogue(const GemmArgs &G, f32x16 (&acc
                         const f32x16 &a = acc[x][2 * p + yy];
                         const int nl = x * 32 + 8 * rq + 4 * g;  // local n of element 0
                         const f32x4 bias = *reinterpret_cast<const f32x4 *>(G.bias + nw0 + nl);
-                        f16x4 v;
+                        f32x4 t = f32x4{a[4 * rq], a[4 * rq + 1], a[4 * rq + 2], a[4 * rq + 3]} + bias;
+                        if constexpr (EPI == EPI_GELU) {
+                            t = gelu_erf256(t);
+                        } else {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            float t = a[4 * rq + e] + bias[e];
-                            if constexpr (EPI == EPI_GELU) t = gelu_erf256(t);
-                            else t = (nw0 + nl + e) < G.scale_cols ? t * G.scale : t;
-                            v[e] = (_Float16)t;
+                            for (int e = 0; e < 4; ++e) t[e] = (nw0 + nl + e) < G.scale_cols ? t[e] * G.scale : t[e];
                         }
+                        const f16x4 v = f16x4{(_Float16)t[0], (_Float16)t[1], (_Float16)t[2], (_Float16)t[3]};
                         *reinterpret_cast<f16x4 *>(slab + (yy * 32 + i) * LS + nl) = v;
                     }
             __syncthreads();
