@@ -167,17 +167,18 @@ __global__ void __launch_bounds__(G256_THREADS, 2) gemm256_f16_kernel(const Gemm
 
     if (!ABLATE || (G.debug_mode & 16)) {
         // product path: ping-pong pipeline of pipe256.h (debug_mode 16 + bits: its ablations)
-        Pipe256T<ABLATE> P;
+        Pipe256T<PipeSrcFixed, ABLATE> P;
         P.init(smem, w, l);
         P.dbg = G.debug_mode;
+        P.S.dbg = ABLATE ? G.debug_mode : 0;
         const int m0 = (ABLATE && (G.debug_mode & 4)) ? 0 : m0_, n0 = (ABLATE && (G.debug_mode & 4)) ? 0 : n0_;
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                const int r = Pipe256::stage_row(w, l, j), ch = Pipe256::stage_chunk(r, l);
-                P.src[h][j] = G.A + (size_t)(m0 + pipe_a_tile_row(h, r)) * G.lda + ch;
-                P.src[2 + h][j] = G.B + (size_t)(n0 + pipe_b_tile_row(h, r)) * G.ldb + ch;
+                const int r = pipe_stage_row(w, l, j), ch = pipe_stage_chunk(r, l);
+                P.S.src[h][j] = G.A + (size_t)(m0 + pipe_a_tile_row(h, r)) * G.lda + ch;
+                P.S.src[2 + h][j] = G.B + (size_t)(n0 + pipe_b_tile_row(h, r)) * G.ldb + ch;
             }
         P.run(G.K / TK, acc);
     } else {

@@ -329,7 +329,7 @@ int ip_topk_fast(const float *d_x, int64_t n, int64_t row_base, const float *d_q
 }
 
 // ANCE_SEARCH=exact forces the fp32-MFMA scan everywhere (A/B and cross-checks); default: the
-// two-precision path whenever the shape is eligible (d % 64 == 0, k <= 256, n >= 4096).
+// two-precision path whenever the shape is eligible (d % 128 == 0, k <= 256, n >= 4096).
 static bool fast_enabled() {
     static int v = -1;
     if (v < 0) {

@@ -26,6 +26,7 @@
 // eps = 1.25 * [ (2^-10 + 2.1 d 2^-24) ||q|| max||x||  +  2^-24 sqrt(d) (||q|| + max||x||) ].
 #include "common.h"
 #include "topk_common.h"
+#include "pipe256.h"
 
 namespace ance {
 namespace {
@@ -114,6 +115,28 @@ __device__ __forceinline__ float exact_ip_lds(const float *q_lds, const float *x
     return s;
 }
 
+// Source policy of the streamed main loop (pipe256.h): queries at fixed per-lane pointers, corpus rows
+// addressed from the tile origin p0 (clamped to the last row; rows past n are masked in the filter).
+// K-tile t >= NK belongs to the next corpus tile (p0 + 256).
+struct FastSrc {
+    const _Float16 *q2, *x2;  // uniform bases
+    uint32_t qoff[2][2];      // per-lane offsets (halves) of the query pieces: (clamped row) * d + chunk
+    uint32_t p0, n_last;
+    int rs, ch, w, d, NK;     // rs = lane >> 3 (row inside a piece), ch = source chunk (same for both pieces)
+    template <int TYPE, int J>
+    __device__ __forceinline__ const _Float16 *addr(int t) const {
+        const bool nxt = t >= NK;
+        const int kk = nxt ? t - NK : t;
+        if constexpr (TYPE < 2) {
+            return q2 + (qoff[TYPE][J] + (uint32_t)(kk * 64));
+        } else {
+            const int r = (w + 8 * J) * 8 + rs;  // row of the half-tile
+            const uint32_t row = min(p0 + (nxt ? 256u : 0u) + (uint32_t)pipe_b_tile_row(TYPE - 2, r), n_last);
+            return x2 + ((size_t)row * d + (uint32_t)(kk * 64 + ch));
+        }
+    }
+};
+
 __global__ void __launch_bounds__(F_THREADS, 2) ip_topk_fast_kernel(const FastParams P) {
     extern __shared__ __attribute__((aligned(16))) float smem_f[];
     _Float16 *smem = reinterpret_cast<_Float16 *>(smem_f);
@@ -149,80 +172,42 @@ __global__ void __launch_bounds__(F_THREADS, 2) ip_topk_fast_kernel(const FastPa
         eps2_s[tid] = 2.0f * (P.slack_rel * qn * xm + P.slack_abs * (qn + xm));
     }
 
-    // staging geometry of gemm256_f16.hip: wave w moves row groups w, w+8, w+16, w+24 (8 rows each)
-    const int rg = l >> 3, slot = l & 7;
-    const _Float16 *srcQ[4];
-    int chs[4];
+    // ---- main loop: the ping-pong pipeline of pipe256.h, streamed across this split's corpus tiles ----
+    // A operand = the block's 256 queries (re-read from L2 for every corpus tile), B operand = corpus
+    // rows.  K-tile index t of the tile being computed; t >= NK addresses the next corpus tile, so the
+    // LDS-DMA prefetch (5-6 phases ahead) runs through the filter step into the next tile.
+    Pipe256T<FastSrc> pipe;
+    pipe.init(smem, w, l);
+    {
+        FastSrc &S = pipe.S;
+        S.q2 = P.q2; S.x2 = P.x2; S.d = d; S.n_last = P.n - 1; S.NK = d / FK; S.p0 = (uint32_t)t0 * FP;
+        S.w = w; S.rs = l >> 3;
+        S.ch = pipe_stage_chunk(pipe_stage_row(w, l, 0), l);  // rows of piece 1 are 64 further: same swizzle
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int row = (j * 8 + w) * 8 + rg;
-        chs[j] = (slot ^ ((row >> 1) & 7)) * 8;
-        srcQ[j] = P.q2 + (size_t)min(q0 + row, P.nq - 1) * d + chs[j];
-    }
-    int nrow[2], nsw[2], mrow[4], msw[4];
+        for (int h = 0; h < 2; ++h)
 #pragma unroll
-    for (int x = 0; x < 2; ++x) {
-        nrow[x] = wn * 64 + x * 32 + i;
-        nsw[x] = (nrow[x] >> 1) & 7;
-    }
-#pragma unroll
-    for (int y = 0; y < 4; ++y) {
-        mrow[y] = wm * 128 + y * 32 + i;
-        msw[y] = (mrow[y] >> 1) & 7;
+            for (int j = 0; j < 2; ++j) {
+                const int r = pipe_stage_row(w, l, j);
+                S.qoff[h][j] = min(q0 + (uint32_t)pipe_a_tile_row(h, r), P.nq - 1) * (uint32_t)d + S.ch;
+            }
     }
     const int NK = d / FK;
+    int *epoch_s = cnt_s + FQ;  // last tile (1-based) in which some wave asked for a prune
+    if (tid == 0) *epoch_s = 0;
+    pipe.prologue();  // also publishes thr_s / cnt_s / eps2_s / epoch_s
 
     for (int t = t0; t < t1; ++t) {
         const uint32_t p0 = (uint32_t)t * FP;
-        const _Float16 *srcX[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int row = (j * 8 + w) * 8 + rg;
-            srcX[j] = P.x2 + (size_t)min(p0 + row, P.n - 1) * d + chs[j];
-        }
-        auto stage_issue = [&](int kt, int buf) {
-            const int offq = kt * FK, offx = kt * FK;
-            _Float16 *sa = smem + buf * F_STAGE_HALVES;
-            _Float16 *sb = sa + F_OPER_HALVES;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int piece = ((j * 8 + w) * 8) * FK;
-                __builtin_amdgcn_global_load_lds((glb_void_t *)(srcQ[j] + offq), (lds_void_t *)(sa + piece), 16, 0, 0);
-                __builtin_amdgcn_global_load_lds((glb_void_t *)(srcX[j] + offx), (lds_void_t *)(sb + piece), 16, 0, 0);
-            }
-        };
-
+        pipe.S.p0 = p0;
         f32x16 acc[2][4];
 #pragma unroll
         for (int x = 0; x < 2; ++x)
 #pragma unroll
             for (int y = 0; y < 4; ++y) acc[x][y] = f32x16{0};
-
-        stage_issue(0, 0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        for (int kt = 0; kt < NK; ++kt) {
-            const int buf = kt & 1;
-            if (kt + 1 < NK) stage_issue(kt + 1, buf ^ 1);
-            const _Float16 *sa = smem + buf * F_STAGE_HALVES;  // queries (m)
-            const _Float16 *sb = sa + F_OPER_HALVES;           // passages (n)
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const int ch = 2 * s + g;
-                f16x8 fn[2], fm[4];
-#pragma unroll
-                for (int x = 0; x < 2; ++x) fn[x] = *reinterpret_cast<const f16x8 *>(sb + nrow[x] * FK + ((ch ^ nsw[x]) * 8));
-#pragma unroll
-                for (int y = 0; y < 4; ++y) fm[y] = *reinterpret_cast<const f16x8 *>(sa + mrow[y] * FK + ((ch ^ msw[y]) * 8));
-#pragma unroll
-                for (int x = 0; x < 2; ++x)
-#pragma unroll
-                    for (int y = 0; y < 4; ++y)
-                        acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fn[x], fm[y], acc[x][y], 0, 0, 0);
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-        }
+        pipe.enter();
+        if (t + 1 < t1) pipe.tiles_streaming(NK, acc);
+        else pipe.tiles_final(NK, acc);
+        pipe.leave();
 
         // ---- filter: keep every row whose approximate score is within 2 eps of the k-th best -------
         // acc[x][y][r]: passage = p0 + wn*64 + x*32 + (r&3) + 8 (r>>2) + 4 g ; query = q0 + wm*128 + y*32 + i
@@ -245,8 +230,21 @@ __global__ void __launch_bounds__(F_THREADS, 2) ip_topk_fast_kernel(const FastPa
                     }
                 }
         }
-        __syncthreads();
         // ---- prune buffers that could overflow on the next tile (approximate keys) --------------------
+        // Barriers here are raw s_barriers: a __syncthreads would drain the LDS-DMA prefetch of the next
+        // tile (vmcnt(0)).  Only when some buffer really needs a prune (a few times per query, early in
+        // the scan) do all waves retire their candidate stores before anybody reads them back.
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        {
+            const int c32 = cnt_s[w * 32 + (l & 31)];
+            if (__ballot(c32 > F_C - FP) != 0ull && l == 0) *epoch_s = t + 1;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (*epoch_s != t + 1) continue;  // block-uniform
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
         for (int qq = 0; qq < 32; ++qq) {
             const int ql = w * 32 + qq;
             const int n_c = __builtin_amdgcn_readfirstlane(cnt_s[ql]);
@@ -286,7 +284,7 @@ __global__ void __launch_bounds__(F_THREADS, 2) ip_topk_fast_kernel(const FastPa
                 }
             }
         }
-        __syncthreads();
+        // thr_s / cnt_s updates are published by the barriers of the next tile's main loop
     }
     __syncthreads();
 
@@ -341,7 +339,7 @@ struct FastPlan {
 };
 
 bool make_fast_plan(int64_t n, int64_t nq, int d, int k, FastPlan *pl) {
-    if (d < 64 || d % 64 || k < 1 || k > 256 || n < 4096 || n >= (1ll << 32) || nq < 1) return false;
+    if (d < 128 || d % 128 || k < 1 || k > 256 || n < 4096 || n >= (1ll << 32) || nq < 1) return false;
     pl->n_tiles_p = (int)((n + FP - 1) / FP);
     const int64_t nqt = (nq + FQ - 1) / FQ;
     const int64_t qct = nqt < 128 ? nqt : 128;

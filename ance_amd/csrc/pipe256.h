@@ -9,27 +9,31 @@
 // blocks {h, h+2, h+4, h+6} of the B tile (x = h).  A K-tile is consumed in four phases, one
 // 64 x 32 output quadrant of every wave each:
 //
-//   phase c0: read A-half0 + B-half0   MFMA acc[0][0..1]  + stage B-half1 of tile t+1
-//   phase c1: read B-half1             MFMA acc[1][0..1]  + stage A-half1 of tile t+1
-//   phase c2: read A-half1             MFMA acc[1][2..3]  + stage A-half0 of tile t+2
-//   phase c3: (B-half0 kept in VGPRs)  MFMA acc[0][2..3]  + stage B-half0 of tile t+2
+//   phase c0: read A-half0 + B-half0   MFMA acc[0][0..1]  + stage B-half0 of tile t+1
+//   phase c1: read B-half1             MFMA acc[1][0..1]  + stage A-half0 of tile t+2
+//   phase c2: read A-half1             MFMA acc[1][2..3]  + stage B-half1 of tile t+2
+//   phase c3: read B-half0 (again)     MFMA acc[0][2..3]  + stage A-half1 of tile t+2
 //
-// Every phase is  { ds_reads ; s_waitcnt vmcnt(6) }  s_barrier  { 8 MFMA with 2 global_load_lds
-// issued between them }  s_barrier.  The four waves with wm = 1 run one barrier behind the four
-// with wm = 0, so on every SIMD one wave is in its MFMA half-phase while the other one reads LDS:
-// the matrix pipe never waits for a ds_read, and staged half-tiles stay in flight across barriers
-// (5-6 phases ahead, counted vmcnt, never 0 in steady state).  The LDS-DMAs sit in the MFMA
-// half-phase because their issue cost (60-185 cycles each beside ds_reads) does not fit in the read
-// half-phase; measured on 8192^3: 935 -> see DESIGN.md.
+// Every phase is  { ds_reads }  s_barrier  { 8 MFMA with 2 global_load_lds issued between them }
+// s_barrier, plus ONE s_waitcnt vmcnt(4) per K-tile (end of the c3 reads).  The four waves with
+// wm = 1 run one barrier behind the four with wm = 0, so on every SIMD one wave is in its MFMA
+// half-phase while the other one reads LDS: the matrix pipe never waits for a ds_read, and staged
+// half-tiles stay in flight across barriers (4-7 phases ahead, counted vmcnt, never 0 in steady
+// state).  Where the LDS-DMAs are issued was chosen by cycle counts (profiles/
+// r01_gemm_schedule_variants_cycles.txt): between the MFMAs 1.36 M cycles per XCD on 8192^3, in the
+// read half-phase 1.57-1.96 M, one in each 1.79 M, at the start / end of the MFMA half-phase 1.48-1.50 M;
+// the wm stagger itself is worth 1.36 vs 1.78 M and the two-phase loop this replaced took 1.88 M.
 //
-// Hazards (slot = interval between two barriers; wm=0 reads in slot 2p and computes in slot 2p+1,
-// wm=1 one slot later):
-//   RAW  a half-tile read in phase p was staged in phase p-5 (or p-6); every wave retires its own
-//        pieces with vmcnt(6) at the end of its read half-phase p-1 (three younger half-tiles may stay
-//        in flight), i.e. before the barrier that precedes the first read.
-//   WAR  a half-tile read in phase p is restaged in phase p+2 at the earliest: the last ds_read of
-//        it (wm=1, slot 2p+1) has returned before that wave's MFMAs of slot 2p+2 finish (they consume
-//        it), and the barrier ending slot 2p+2 precedes the first restage (wm=0, slot 2p+5).
+// Hazards (slot = interval between two barriers; wm=0 reads phase p in slot 2p and computes it in
+// slot 2p+1, wm=1 one slot later):
+//   RAW  the wait at the end of the c3 reads of tile t-1 leaves at most two half-tiles in flight
+//        (A-half0 and B-half1 of tile t+1, the last ones issued): every wave has then retired its
+//        pieces of all four half-tiles of tile t, and the barrier that follows publishes them before
+//        the first read of tile t.
+//   WAR  a half-tile last read in phase p is restaged in the MFMA half-phase of phase p+1 at the
+//        earliest (wm=0: slot 2p+3).  The last ds_read of it (wm=1, slot 2p+1) has returned before
+//        that wave's MFMAs of slot 2p+2 are issued (they consume it), and the barrier ending slot
+//        2p+2 comes before slot 2p+3.
 // Needs NK >= 2 K-tiles.  The last two tiles are peeled (nothing left to stage, smaller counts).
 #pragma once
 #include "common.h"
@@ -49,19 +53,33 @@ constexpr size_t PIPE_LDS_BYTES = (size_t)2 * PIPE_BUF_HALVES * sizeof(_Float16)
 __device__ __forceinline__ int pipe_a_tile_row(int h, int r) { return (((r >> 6) * 2 + h) << 6) + (r & 63); }
 __device__ __forceinline__ int pipe_b_tile_row(int h, int r) { return (((r >> 5) * 2 + h) << 5) + (r & 31); }
 
-// DBG compiles measurement ablations in (dbg bit 0: always re-read K-tiles 0/1, bit 1: no MFMA, bit 3: no staging);
-// the product instantiation is Pipe256<false>.
-template <bool DBG = false>
-struct Pipe256T {
-    // per-lane source pointers at k = 0 of the two 1 KiB pieces this wave stages per half-tile:
-    // piece j covers half-tile rows (w + 8 j) * 8 + (lane >> 3), LDS slot lane & 7, and must point at
-    // 16-byte chunk  (lane & 7) ^ ((row >> 1) & 7)  of that row (the XOR swizzle lives in the source
-    // address because the LDS image of an LDS-DMA is lane-linear).
+// Staging geometry: a half-tile is staged as 16 pieces of 1 KiB; wave w issues pieces w and w + 8.
+// Piece j of wave w covers half-tile rows (w + 8 j) * 8 + (lane >> 3); lane L fills LDS slot L & 7 of
+// its row and must read 16-byte chunk (L & 7) ^ ((row >> 1) & 7) of it (the XOR swizzle lives in the
+// source address because the LDS image of an LDS-DMA is lane-linear).
+__device__ __forceinline__ int pipe_stage_row(int w, int l, int j) { return (w + 8 * j) * 8 + (l >> 3); }
+__device__ __forceinline__ int pipe_stage_chunk(int row, int l) { return ((l & 7) ^ ((row >> 1) & 7)) * 8; }
+
+// Source policy of a plain GEMM: fixed per-lane pointers at k = 0, K-tile t at +64 t halves.
+struct PipeSrcFixed {
     const _Float16 *src[4][2];  // [A0 A1 B0 B1][piece]
+    int dbg = 0;                // measurement ablation bit 0: always re-read K-tiles 0/1
+    template <int TYPE, int J>
+    __device__ __forceinline__ const _Float16 *addr(int t) const {
+        return src[TYPE][J] + ((dbg & 1) ? (t & 1) * 64 : t * 64);
+    }
+};
+
+// SRC provides  template <int TYPE, int J> const _Float16 *addr(int t)  : the per-lane source address of
+// piece J of half-tile TYPE (0 A-half0, 1 A-half1, 2 B-half0, 3 B-half1) of K-tile t.
+// DBG compiles measurement ablations in (dbg bit 1: no MFMA, bit 3: no staging); product code uses DBG = false.
+template <class SRC, bool DBG = false>
+struct Pipe256T {
+    SRC S;
     _Float16 *smem;
     int w, dbg = 0;
     int ra[2], rb, kx[4];  // per-lane read offsets (halves)
-    f16x8 fa[2][4], fb[2][4];
+    f16x8 fa[2][4], fb[4];
 
     __device__ __forceinline__ void init(_Float16 *smem_, int w_, int l) {
         smem = smem_;
@@ -75,17 +93,11 @@ struct Pipe256T {
         rb = (wn * 32 + i) * 64;
     }
 
-    // source chunk (in halves) for staging lane l
-    static __device__ __forceinline__ int stage_row(int w, int l, int j) { return (w + 8 * j) * 8 + (l >> 3); }
-    static __device__ __forceinline__ int stage_chunk(int row, int l) { return ((l & 7) ^ ((row >> 1) & 7)) * 8; }
-
     template <int TYPE, int J>
     __device__ __forceinline__ void stage_piece(int t) {
         if (DBG && (dbg & 8)) return;            // ablation: stage nothing (prologue included)
         _Float16 *dst = smem + (t & 1) * PIPE_BUF_HALVES + TYPE * PIPE_HALF_HALVES + (w + 8 * J) * 512;
-        int k0 = t * 64;
-        if (DBG && (dbg & 1)) k0 = (t & 1) * 64;  // ablation: re-read the first two K-tiles (always cache hits)
-        __builtin_amdgcn_global_load_lds((pipe_glb_t *)(src[TYPE][J] + k0), (pipe_lds_t *)dst, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((pipe_glb_t *)S.template addr<TYPE, J>(t), (pipe_lds_t *)dst, 16, 0, 0);
     }
     template <int TYPE>
     __device__ __forceinline__ void stage(int t) {
@@ -104,7 +116,7 @@ struct Pipe256T {
     __device__ __forceinline__ void read_b(int t) {
         const _Float16 *base = smem + (t & 1) * PIPE_BUF_HALVES + (2 + H) * PIPE_HALF_HALVES;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) fb[H][s] = *reinterpret_cast<const f16x8 *>(base + rb + kx[s]);
+        for (int s = 0; s < 4; ++s) fb[s] = *reinterpret_cast<const f16x8 *>(base + rb + kx[s]);
     }
     // MFMA half-phase: barrier, 8 MFMAs with the two LDS-DMA pieces of half-tile STAGE (of K-tile ts)
     // issued in the shadow of the matrix pipe (an LDS-DMA costs 60-185 issue cycles in a read
@@ -120,10 +132,10 @@ struct Pipe256T {
 #pragma unroll
             for (int yy = 0; yy < 2; ++yy) {
                 if (DBG && (dbg & 2)) {  // ablation: keep the LDS reads alive, skip the matrix pipe
-                    asm volatile("" ::"v"(fb[X][s]), "v"(fa[yy][s]));
+                    asm volatile("" ::"v"(fb[s]), "v"(fa[yy][s]));
                 } else {
                     acc[X][2 * YH + yy] =
-                        __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[X][s], fa[yy][s], acc[X][2 * YH + yy], 0, 0, 0);
+                        __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[s], fa[yy][s], acc[X][2 * YH + yy], 0, 0, 0);
                 }
             }
             if constexpr (STAGE >= 0) {
@@ -144,40 +156,64 @@ struct Pipe256T {
     // MODE 0: steady state (tiles t+1, t+2 exist); 1: t = NK-2; 2: t = NK-1
     template <int MODE>
     __device__ __forceinline__ void tile(int t, f32x16 (&acc)[2][4]) {
-        // c0 (the wait at the end of each read half-phase retires what the NEXT phase reads)
+        // c0
         read_a<0>(t);
         read_b<0>(t);
-        if constexpr (MODE <= 1) PIPE_WAIT_VM(6); else PIPE_WAIT_VM(2);
-        mfma<0, 0, (MODE <= 1 ? 3 : -1)>(acc, t + 1);
+        mfma<0, 0, (MODE <= 1 ? 2 : -1)>(acc, t + 1);
         // c1
         read_b<1>(t);
-        if constexpr (MODE <= 1) PIPE_WAIT_VM(6); else PIPE_WAIT_VM(0);
-        mfma<1, 0, (MODE <= 1 ? 1 : -1)>(acc, t + 1);
+        mfma<1, 0, (MODE == 0 ? 0 : -1)>(acc, t + 2);
         // c2
         read_a<1>(t);
-        mfma<1, 1, (MODE == 0 ? 0 : -1)>(acc, t + 2);
-        // c3
-        if constexpr (MODE == 0) PIPE_WAIT_VM(6);
-        if constexpr (MODE == 1) PIPE_WAIT_VM(4);
-        mfma<0, 1, (MODE == 0 ? 2 : -1)>(acc, t + 2);
+        mfma<1, 1, (MODE == 0 ? 3 : -1)>(acc, t + 2);
+        // c3: the wait retires every half-tile of tile t+1 (see RAW above)
+        read_b<0>(t);
+        if constexpr (MODE == 0) PIPE_WAIT_VM(4);
+        if constexpr (MODE == 1) PIPE_WAIT_VM(0);
+        mfma<0, 1, (MODE == 0 ? 1 : -1)>(acc, t + 2);
     }
 
-    // Whole K loop of one output tile.  All 512 threads; on return every wave has passed the same
-    // number of barriers and no LDS-DMA is in flight.
-    __device__ __forceinline__ void run(int NK, f32x16 (&acc)[2][4]) {
-        stage<0>(0); stage<2>(0); stage<3>(0); stage<1>(0); stage<0>(1); stage<2>(1);
-        PIPE_WAIT_VM(8);
+    // ---- building blocks of a K loop (all 512 threads) ----------------------------------------------
+    // prologue: stage K-tile 0 and A0 B1 A1 of K-tile 1 (what the steady state has issued when a tile
+    // starts), publish tile 0
+    __device__ __forceinline__ void prologue() {
+        stage<0>(0); stage<2>(0); stage<3>(0); stage<1>(0); stage<0>(1); stage<3>(1); stage<1>(1);
+        PIPE_WAIT_VM(6);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
-        if (w >= 4) __builtin_amdgcn_s_barrier();  // wm = 1 runs one barrier behind
         __builtin_amdgcn_sched_barrier(0);
-        for (int t = 0; t < NK - 2; ++t) tile<0>(t, acc);
-        tile<1>(NK - 2, acc);
-        tile<2>(NK - 1, acc);
+    }
+    // enter / leave the staggered section: wm = 1 runs one barrier behind wm = 0 in between
+    __device__ __forceinline__ void enter() {
+        __builtin_amdgcn_sched_barrier(0);
+        if (w >= 4) __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    __device__ __forceinline__ void leave() {
+        __builtin_amdgcn_sched_barrier(0);
         if (w < 4) __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
     }
+    // K-tiles 0..NK-1 of a stream that CONTINUES (the source policy maps t >= NK onto what follows):
+    // on return K-tiles NK and NK+1 are staged exactly as the prologue leaves tiles 0 and 1 (the wait
+    // of the last c3 has retired tile NK).
+    __device__ __forceinline__ void tiles_streaming(int NK, f32x16 (&acc)[2][4]) {
+        for (int t = 0; t < NK; ++t) tile<0>(t, acc);
+    }
+    // K-tiles 0..NK-1 of a stream that ENDS: nothing beyond NK-1 is staged, no LDS-DMA left in flight.
+    __device__ __forceinline__ void tiles_final(int NK, f32x16 (&acc)[2][4]) {
+        for (int t = 0; t < NK - 2; ++t) tile<0>(t, acc);
+        tile<1>(NK - 2, acc);
+        tile<2>(NK - 1, acc);
+    }
+
+    // Whole K loop of one output tile.  On return every wave has passed the same number of barriers.
+    __device__ __forceinline__ void run(int NK, f32x16 (&acc)[2][4]) {
+        prologue();
+        enter();
+        tiles_final(NK, acc);
+        leave();
+    }
 };
-using Pipe256 = Pipe256T<false>;
 
 }  // namespace ance
