@@ -345,7 +345,7 @@ bool make_fast_plan(int64_t n, int64_t nq, int d, int k, FastPlan *pl) {
     const int64_t qct = nqt < 128 ? nqt : 128;
     pl->qc = qct * FQ;
     int S = 1;
-    while (qct * S < 512 && S < 32) S <<= 1;
+    while (qct * S < 256 && S < 32) S <<= 1;  // one workgroup per CU: more splits only add prologues and re-scoring
     if (const char *e = getenv("ANCE_FAST_SPLITS")) {  // tuning knob (power of two, 1..32)
         const int v = atoi(e);
         if (v >= 1 && v <= 32 && (v & (v - 1)) == 0) S = v;

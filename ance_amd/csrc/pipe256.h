@@ -73,13 +73,15 @@ struct PipeSrcFixed {
 // SRC provides  template <int TYPE, int J> const _Float16 *addr(int t)  : the per-lane source address of
 // piece J of half-tile TYPE (0 A-half0, 1 A-half1, 2 B-half0, 3 B-half1) of K-tile t.
 // DBG compiles measurement ablations in (dbg bit 1: no MFMA, bit 3: no staging); product code uses DBG = false.
-template <class SRC, bool DBG = false>
+// KEEP_B0: hold the B-half0 fragments of a K-tile in 16 more VGPRs from phase c0 to c3 instead of reading
+// them from LDS a second time (the GEMM has the registers, the search filter does not).
+template <class SRC, bool DBG = false, bool KEEP_B0 = false>
 struct Pipe256T {
     SRC S;
     _Float16 *smem;
     int w, dbg = 0;
     int ra[2], rb, kx[4];  // per-lane read offsets (halves)
-    f16x8 fa[2][4], fb[4];
+    f16x8 fa[2][4], fb[4], fbk[KEEP_B0 ? 4 : 1];
 
     __device__ __forceinline__ void init(_Float16 *smem_, int w_, int l) {
         smem = smem_;
@@ -116,7 +118,11 @@ struct Pipe256T {
     __device__ __forceinline__ void read_b(int t) {
         const _Float16 *base = smem + (t & 1) * PIPE_BUF_HALVES + (2 + H) * PIPE_HALF_HALVES;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) fb[s] = *reinterpret_cast<const f16x8 *>(base + rb + kx[s]);
+        for (int s = 0; s < 4; ++s) {
+            const f16x8 v = *reinterpret_cast<const f16x8 *>(base + rb + kx[s]);
+            if constexpr (KEEP_B0 && H == 0) fbk[s] = v;
+            else fb[s] = v;
+        }
     }
     // MFMA half-phase: barrier, 8 MFMAs with the two LDS-DMA pieces of half-tile STAGE (of K-tile ts)
     // issued in the shadow of the matrix pipe (an LDS-DMA costs 60-185 issue cycles in a read
@@ -131,11 +137,11 @@ struct Pipe256T {
         for (int s = 0; s < 4; ++s) {
 #pragma unroll
             for (int yy = 0; yy < 2; ++yy) {
+                const f16x8 &bf = (KEEP_B0 && X == 0) ? fbk[s] : fb[s];
                 if (DBG && (dbg & 2)) {  // ablation: keep the LDS reads alive, skip the matrix pipe
-                    asm volatile("" ::"v"(fb[s]), "v"(fa[yy][s]));
+                    asm volatile("" ::"v"(bf), "v"(fa[yy][s]));
                 } else {
-                    acc[X][2 * YH + yy] =
-                        __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[s], fa[yy][s], acc[X][2 * YH + yy], 0, 0, 0);
+                    acc[X][2 * YH + yy] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf, fa[yy][s], acc[X][2 * YH + yy], 0, 0, 0);
                 }
             }
             if constexpr (STAGE >= 0) {
@@ -167,7 +173,7 @@ struct Pipe256T {
         read_a<1>(t);
         mfma<1, 1, (MODE == 0 ? 3 : -1)>(acc, t + 2);
         // c3: the wait retires every half-tile of tile t+1 (see RAW above)
-        read_b<0>(t);
+        if constexpr (!KEEP_B0) read_b<0>(t);
         if constexpr (MODE == 0) PIPE_WAIT_VM(4);
         if constexpr (MODE == 1) PIPE_WAIT_VM(0);
         mfma<0, 1, (MODE == 0 ? 1 : -1)>(acc, t + 2);
