@@ -136,3 +136,22 @@ def run_generate_new_ann(data_dir, output_dir, model, output_num=0, checkpoint_p
     train_pos, dev_pos = G.load_positive_ids(args)
     random.seed(seed)
     return G.generate_new_ann(args, output_num, checkpoint_path, train_pos, dev_pos, step)
+
+
+def run_reference_preprocess(data_dir, out_data_dir, data_type, tokenizer_cls, max_seq_length=16, max_query_length=8,
+                             model_type="rdot_nll"):
+    """Run the reference's own data/msmarco_data.py ``preprocess`` (32 forked tokenizer processes, split
+    merge, pid2offset / qid2offset, offset-space qrels) with ``tokenizer_cls`` standing in for the
+    pretrained tokenizer class (no vocabulary files offline)."""
+    ref = load_reference()
+    cfg = ref.models.MSMarcoConfigDict[model_type]
+    old = cfg.tokenizer_class
+    cfg.tokenizer_class = tokenizer_cls
+    try:
+        os.makedirs(out_data_dir, exist_ok=True)
+        args = types.SimpleNamespace(data_dir=data_dir, out_data_dir=out_data_dir, model_type=model_type,
+                                     model_name_or_path="unused", max_seq_length=max_seq_length,
+                                     max_query_length=max_query_length, max_doc_character=10000, data_type=data_type)
+        ref.msmarco_data.preprocess(args)
+    finally:
+        cfg.tokenizer_class = old

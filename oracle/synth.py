@@ -116,3 +116,75 @@ def dyadic_rows(rng, n, d=768, levels=8, scale=1.0 / 16):
     """Rows on a coarse dyadic grid: every product and partial sum is exact in fp32,
     so inner products are order independent (test plan 3a)."""
     return (rng.integers(-levels, levels + 1, size=(n, d)).astype(np.float32) * np.float32(scale))
+
+
+# ---- raw (untokenised) MS MARCO-like TSVs + a deterministic toy tokenizer -------------------------
+class ToyTokenizer:
+    """Whitespace tokenizer with RoBERTa's special ids (<s>=0, <pad>=1, </s>=2) and the
+    transformers-2.x ``encode(max_length=...)`` truncation the reference relied on (specials kept).
+    Lets the reference's data/msmarco_data.py and ance_amd.msmarco_data run on identical token ids
+    without any pretrained vocabulary (there is no network)."""
+    sep_token = "</s>"
+    pad_token_id = 1
+
+    @classmethod
+    def from_pretrained(cls, *args, **kwargs):
+        return cls()
+
+    def encode(self, text, add_special_tokens=True, max_length=None, **kwargs):
+        import zlib
+        ids = [4 + zlib.crc32(w.lower().encode("utf8")) % 50000 for w in text.split()]
+        if add_special_tokens:
+            if max_length is not None and len(ids) > max_length - 2:
+                ids = ids[:max(max_length - 2, 0)]
+            return [0] + ids + [2]
+        return ids[:max_length] if max_length is not None else ids
+
+
+def toy_tokenizer_factory():
+    return ToyTokenizer()
+
+
+_WORDS = ("alpha beta gamma delta epsilon zeta eta theta iota kappa lambda mu nu xi omicron pi rho sigma tau "
+          "upsilon phi chi psi omega rock river stone cloud forest engine matrix vector kernel wave").split()
+
+
+def make_raw_msmarco(data_dir, data_type, n_passages=70, n_train=25, n_dev=9, seed=5):
+    """Raw TSVs in the layout data/msmarco_data.py reads (data_type 1: passage; 0: document).
+    Ids are sparse and shuffled, some passages exceed any small max_seq_length, some queries have no
+    label (they must be dropped), one query has two labels."""
+    os.makedirs(data_dir, exist_ok=True)
+    rng = np.random.default_rng(seed)
+
+    def text(lo, hi):
+        return " ".join(_WORDS[int(j)] for j in rng.integers(0, len(_WORDS), size=int(rng.integers(lo, hi))))
+
+    pids = rng.permutation(np.arange(1000, 1000 + 3 * n_passages, 3))[:n_passages].tolist()
+    doc = data_type == 0
+    with open(os.path.join(data_dir, "msmarco-docs.tsv" if doc else "collection.tsv"), "w", encoding="utf-8") as f:
+        for p in pids:
+            if doc:
+                f.write("D%d\thttp://x.org/%d \t%s \t%s\n" % (p, p, text(1, 5), text(3, 60)))
+            else:
+                f.write("%d\t%s \n" % (p, text(3, 40)))
+
+    def queries(fname, qrel_name, n, base, sep):
+        qids = rng.permutation(np.arange(base, base + 2 * n, 2))[:n].tolist()
+        with open(os.path.join(data_dir, fname), "w", encoding="utf-8") as f:
+            for q in qids:
+                f.write("%d\t%s\n" % (q, text(2, 12)))
+        labelled = qids[: max(1, (3 * n) // 4)]
+        with open(os.path.join(data_dir, qrel_name), "w", encoding="utf-8") as f:
+            for j, q in enumerate(labelled):
+                tgt = pids[int(rng.integers(0, len(pids)))]
+                f.write(sep.join([str(q), "0", ("D%d" % tgt) if doc else str(tgt), str(1 if not doc else int(rng.integers(1, 4)))]) + "\n")
+                if j == 1:
+                    tgt2 = pids[int(rng.integers(0, len(pids)))]
+                    f.write(sep.join([str(q), "0", ("D%d" % tgt2) if doc else str(tgt2), "1"]) + "\n")
+
+    if doc:
+        queries("msmarco-doctrain-queries.tsv", "msmarco-doctrain-qrels.tsv", n_train, 500000, " ")
+        queries("msmarco-test2019-queries.tsv", "2019qrels-docs.txt", n_dev, 900000, " ")
+    else:
+        queries("queries.train.tsv", "qrels.train.tsv", n_train, 500000, "\t")
+        queries("queries.dev.small.tsv", "qrels.dev.small.tsv", n_dev, 900000, "\t")

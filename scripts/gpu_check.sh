@@ -8,7 +8,7 @@ export TMPDIR=/tmp
 rocminfo 2>/dev/null | grep -E "Marketing Name|gfx" | head -4 > gpurun_out/device.txt
 nproc >> gpurun_out/device.txt
 echo "== smoke" ; timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1 ; echo "smoke rc=$?" ; tail -3 gpurun_out/smoke.log
-for f in test_gpu_search test_gpu_encoder test_gpu_e2e; do
+for f in test_gpu_search test_gpu_gemm test_gpu_encoder test_gpu_e2e test_gpu_dpr; do
   echo "== $f"
   timeout 1500 python -m pytest tests/$f.py -m gpu -q --timeout 900 -p no:cacheprovider > gpurun_out/$f.log 2>&1
   echo "$f rc=$?"; tail -15 gpurun_out/$f.log

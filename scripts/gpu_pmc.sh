@@ -12,6 +12,8 @@ for what in search encode; do
   cmd="$S"; [ $what = encode ] && cmd="$E"
   echo "== kernel-trace $what"
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/pmc/kt_$what -o kt -- $cmd > gpurun_out/pmc/kt_$what.log 2>&1; echo "rc=$?"
+  echo "== pmc cycles $what (GRBM_GUI_ACTIVE = shader clocks of the dispatch: clock-independent cost, and the clock itself)"
+  timeout 600 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES --kernel-trace --output-format csv -d gpurun_out/pmc/CYCLES_$what -o pmc -- $cmd > gpurun_out/pmc/CYCLES_$what.log 2>&1; echo "rc=$?"
   for c in FETCH_SIZE WRITE_SIZE; do
     echo "== pmc $c $what"
     timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmc/${c}_$what -o pmc -- $cmd > gpurun_out/pmc/${c}_$what.log 2>&1; echo "rc=$?"

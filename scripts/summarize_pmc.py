@@ -46,6 +46,32 @@ if len(sys.argv) > 2:
                         n += 1
         return (tot / n * 1024.0) if n else None  # rocprofv3 reports KB
 
+    def cycles(leg, needle):
+        """(shader cycles per XCD, MFMA-pipe busy fraction, effective clock GHz) per dispatch, from the
+        CYCLES pass: GRBM_GUI_ACTIVE is summed over the 8 XCDs; SQ_VALU_MFMA_BUSY_CYCLES over the 1024 SIMDs;
+        the clock is cycles / the dispatch's own duration in the same run's kernel trace."""
+        d = os.path.join(root, "CYCLES_%s" % leg)
+        gui, busy, dur = [], [], []
+        for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+            with open(f) as fh:
+                for row in csv.DictReader(fh):
+                    if needle not in row.get("Kernel_Name", ""):
+                        continue
+                    if row.get("Counter_Name") == "GRBM_GUI_ACTIVE":
+                        gui.append(float(row["Counter_Value"]) / 8.0)
+                    elif row.get("Counter_Name") == "SQ_VALU_MFMA_BUSY_CYCLES":
+                        busy.append(float(row["Counter_Value"]) / 1024.0)
+        for f in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
+            with open(f) as fh:
+                for row in csv.DictReader(fh):
+                    if needle in row.get("Kernel_Name", ""):
+                        dur.append(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
+        if not gui or not dur:
+            return None
+        g, t = sum(gui) / len(gui), sum(dur) / len(dur)
+        return {"cycles_per_launch": g, "mfma_busy_frac": (sum(busy) / len(busy) / g) if busy else None,
+                "clock_ghz": g / t, "ns_per_launch_under_pmc": t}
+
     out = {}
     for leg, cat, needle in (("encode", "gemm_ffn1", "gemm256_f16_kernel<1"), ("encode", "gemm_qk", "gemm256_f16_kernel<0"),
                              ("encode", "gemm_res32", "gemm256_f16_kernel<2"), ("encode", "gemm_vt", "gemm256_f16_kernel<3"),
@@ -54,7 +80,8 @@ if len(sys.argv) > 2:
         fe, wr = per_dispatch(leg, "FETCH_SIZE", needle), per_dispatch(leg, "WRITE_SIZE", needle)
         if fe is None or wr is None:
             continue
-        out.setdefault(leg, {})[cat] = {"hbm_bytes_per_launch": 2.0 * fe + wr, "fetch_bytes_x2": 2.0 * fe, "write_bytes": wr,
+        out.setdefault(leg, {})[cat] = {"cycles": cycles(leg, needle),
+                                        "hbm_bytes_per_launch": 2.0 * fe + wr, "fetch_bytes_x2": 2.0 * fe, "write_bytes": wr,
                                         "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on tools/abi_probe, same "
                                                 "workload as bench.py; FETCH_SIZE doubled per MI355X_MICROARCH.md (wide reads on gfx950)"}
     with open(sys.argv[2], "w") as f:

@@ -185,9 +185,40 @@ def golden_dpr():
     return dict(top20=hits[19], n_neg=sum(len(v) for v in neg.values()))
 
 
+def golden_preprocess():
+    """The reference's own data/msmarco_data.py ``preprocess`` (passage and document layouts) on seeded
+    raw TSVs with oracle.synth.ToyTokenizer standing in for the pretrained tokenizer: sha256 of every
+    merged output (the split intermediates are covered through the merge)."""
+    import hashlib
+    import shutil
+    import tempfile
+    out = {}
+    for data_type in (1, 0):
+        tmp = tempfile.mkdtemp(prefix="ance_golden_pp_")
+        try:
+            raw, dst = os.path.join(tmp, "raw"), os.path.join(tmp, "out")
+            synth.make_raw_msmarco(raw, data_type, n_passages=70, n_train=25, n_dev=9, seed=5)
+            ref_harness.run_reference_preprocess(raw, dst, data_type, synth.ToyTokenizer, max_seq_length=16,
+                                                 max_query_length=8)
+            files = {}
+            for f in sorted(os.listdir(dst)):
+                if "_split" in f:
+                    continue
+                with open(os.path.join(dst, f), "rb") as fh:
+                    files[f] = hashlib.sha256(fh.read()).hexdigest()
+            out[str(data_type)] = files
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+    with open(os.path.join(OUT, "preprocess.json"), "w") as f:
+        json.dump(dict(raw=dict(n_passages=70, n_train=25, n_dev=9, seed=5), max_seq_length=16, max_query_length=8,
+                       sha256=out), f, indent=1)
+    return {k: len(v) for k, v in out.items()}
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     info = dict(encoder=golden_encoder(), postsearch=golden_postsearch(), e2e=golden_end_to_end(), dpr=golden_dpr(),
+                preprocess=golden_preprocess(),
                 torch=torch.__version__, numpy=np.__version__)
     with open(os.path.join(OUT, "manifest.json"), "w") as f:
         json.dump(info, f, indent=1)
