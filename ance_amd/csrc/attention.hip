@@ -20,7 +20,7 @@ constexpr int ATT_THREADS = 256;
 
 __device__ __forceinline__ int kswz(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
 
-__global__ void __launch_bounds__(ATT_THREADS) attention_kernel(const AttnArgs A) {
+__global__ void __launch_bounds__(ATT_THREADS, 4) attention_kernel(const AttnArgs A) {
     extern __shared__ __attribute__((aligned(16))) float smem_f[];
     const int s = blockIdx.x / A.n_heads;
     const int h = blockIdx.x - s * A.n_heads;
@@ -36,46 +36,62 @@ __global__ void __launch_bounds__(ATT_THREADS) attention_kernel(const AttnArgs A
     const int w = tid >> 6, l = tid & 63, g = l >> 5, i = l & 31;
     const int H = A.n_heads * HD;
 
+    // Q fragment of this wave's first query block: requested before the staging so that its latency
+    // overlaps the K / V^T loads (B operand: lane (query i, group g) holds head dims 32 g + 8 s .. + 8)
+    const int q_end = A.cls_only ? 1 : T;  // last layer: only the [CLS] query feeds the head
+    f16x8 qf[4];
+    if (w * 32 < q_end) {
+        const _Float16 *qp = A.qk + (size_t)(tok0 + min(w * 32 + i, T - 1)) * A.ld_qk + h * HD + 32 * g;
+#pragma unroll
+        for (int sx = 0; sx < 4; ++sx) qf[sx] = *reinterpret_cast<const f16x8 *>(qp + sx * 8);
+    }
+
     // ---- stage K (rows = keys) and V^T (rows = head dims) into LDS; rows/cols >= T are zeroed ---
+    // Eight independent 16-byte loads per thread (4 of K, 4 of V^T: both tiles have Tk * 8 chunks) are in
+    // flight before the first LDS store -- a plain load -> store loop waits one full memory latency per
+    // iteration, and this kernel is latency-bound (a (sequence, head) is ~0.7 MFLOP).
     {
         const _Float16 *kbase = A.qk + (size_t)tok0 * A.ld_qk + H + h * HD;
-        for (int e = tid; e < Tk * 8; e += ATT_THREADS) {
-            const int row = e >> 3, ch = e & 7;
-            f16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (row < T) v = *reinterpret_cast<const f16x8 *>(kbase + (size_t)row * A.ld_qk + ch * 8);
-            *reinterpret_cast<f16x8 *>(Ks + row * HD + kswz(row, ch) * 8) = v;
-        }
         const _Float16 *vbase = A.vt + (size_t)(h * HD) * A.ld_vt + vcol0;
         const int nch = Tk >> 3;  // 16-byte chunks per V^T row
-        for (int e = tid; e < HD * nch; e += ATT_THREADS) {
-            const int dd = e / nch, ch = e - dd * nch;
-            f16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-            const int key0 = ch * 8;
-            if (key0 < T) {
-                v = *reinterpret_cast<const f16x8 *>(vbase + (size_t)dd * A.ld_vt + key0);
+        const int ne = Tk * 8;    // chunks of K ([Tk][8]) = chunks of V^T ([64][Tk / 8])
+        for (int e0 = tid; e0 < ne; e0 += 4 * ATT_THREADS) {
+            f16x8 kv[4], vv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = e0 + u * ATT_THREADS, row = e >> 3, ch = e & 7;
+                const int dd = e / nch, key0 = (e - dd * nch) * 8;
+                kv[u] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                vv[u] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                if (e < ne && row < T) kv[u] = *reinterpret_cast<const f16x8 *>(kbase + (size_t)row * A.ld_qk + ch * 8);
+                if (e < ne && key0 < T) vv[u] = *reinterpret_cast<const f16x8 *>(vbase + (size_t)dd * A.ld_vt + key0);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = e0 + u * ATT_THREADS, row = e >> 3, ch = e & 7;
+                const int dd = e / nch, key0 = (e - dd * nch) * 8;
+                if (e >= ne) continue;
+                *reinterpret_cast<f16x8 *>(Ks + row * HD + kswz(row, ch) * 8) = kv[u];
                 if (key0 + 8 > T) {
 #pragma unroll
                     for (int j = 0; j < 8; ++j)
-                        if (key0 + j >= T) v[j] = (_Float16)0.0f;
+                        if (key0 + j >= T) vv[u][j] = (_Float16)0.0f;
                 }
+                _Float16 *dst = Vs + dd * vld + key0;  // 8-byte aligned
+                *reinterpret_cast<f16x4 *>(dst) = f16x4{vv[u][0], vv[u][1], vv[u][2], vv[u][3]};
+                *reinterpret_cast<f16x4 *>(dst + 4) = f16x4{vv[u][4], vv[u][5], vv[u][6], vv[u][7]};
             }
-            _Float16 *dst = Vs + dd * vld + key0;  // 8-byte aligned
-            *reinterpret_cast<f16x4 *>(dst) = f16x4{v[0], v[1], v[2], v[3]};
-            *reinterpret_cast<f16x4 *>(dst + 4) = f16x4{v[4], v[5], v[6], v[7]};
         }
     }
     __syncthreads();
 
     const int nkb = Tk >> 5;
-    // cls_only (last layer): only the [CLS] query feeds the head, so one wave does one 32-query block
-    const int q_end = A.cls_only ? 1 : T;
     for (int qb0 = w * 32; qb0 < q_end; qb0 += 128) {
-        // Q fragment (B operand): lane (query i, group g) holds head dims 32 g + 8 s .. + 8, s = 0..3
-        const int qrow = min(qb0 + i, T - 1);
-        const _Float16 *qp = A.qk + (size_t)(tok0 + qrow) * A.ld_qk + h * HD + 32 * g;
-        f16x8 qf[4];
+        if (qb0 != w * 32) {  // later query blocks of long sequences (the first one was prefetched above)
+            const _Float16 *qp = A.qk + (size_t)(tok0 + min(qb0 + i, T - 1)) * A.ld_qk + h * HD + 32 * g;
 #pragma unroll
-        for (int sx = 0; sx < 4; ++sx) qf[sx] = *reinterpret_cast<const f16x8 *>(qp + sx * 8);
+            for (int sx = 0; sx < 4; ++sx) qf[sx] = *reinterpret_cast<const f16x8 *>(qp + sx * 8);
+        }
 
         float m_run = -INFINITY, l_run = 0.0f;
         f32x16 o0 = {0}, o1 = {0};

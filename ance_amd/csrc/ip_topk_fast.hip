@@ -169,7 +169,10 @@ __global__ void __launch_bounds__(F_THREADS, 2) ip_topk_fast_kernel(const FastPa
         thr_s[tid] = -INFINITY;
         cnt_s[tid] = 0;
         const float qn = qg < P.nq ? P.qnorm[qg] : 0.0f, xm = P.xmax[0];
-        eps2_s[tid] = 2.0f * (P.slack_rel * qn * xm + P.slack_abs * (qn + xm));
+        // the bound assumes no fp16 overflow: |x_j| <= ||x||, so norms <= 65504 exclude it.  Otherwise eps = inf
+        // keeps every row until the buffer overflows and the chunk is redone by the exact scan.
+        const bool fp16_ok = qn <= 65504.0f && xm <= 65504.0f;  // false for NaN too
+        eps2_s[tid] = fp16_ok ? 2.0f * (P.slack_rel * qn * xm + P.slack_abs * (qn + xm)) : INFINITY;
     }
 
     // ---- main loop: the ping-pong pipeline of pipe256.h, streamed across this split's corpus tiles ----
@@ -212,11 +215,24 @@ __global__ void __launch_bounds__(F_THREADS, 2) ip_topk_fast_kernel(const FastPa
         // ---- filter: keep every row whose approximate score is within 2 eps of the k-th best -------
         // acc[x][y][r]: passage = p0 + wn*64 + x*32 + (r&3) + 8 (r>>2) + 4 g ; query = q0 + wm*128 + y*32 + i
         const uint32_t pw0 = p0 + wn * 64 + 4 * g;
+        const bool ragged = p0 + FP > P.n;  // uniform: rows past n were staged as copies of row n-1
 #pragma unroll
         for (int y = 0; y < 4; ++y) {
             const int ql = wm * 128 + y * 32 + i;
             const bool qv = (q0 + ql) < P.nq;
             const float thr = thr_s[ql];  // -inf until the first prune
+            // Once the threshold is set almost no row passes (about k + band of 8.8 M per query): take the
+            // maximum of the lane's 32 scores first and skip the whole group when no lane of the wave has
+            // a candidate -- 16 v_max3 instead of 32 compare-and-branch sequences.  Scores are finite
+            // (fp16_ok above), so the maximum loses nothing.  Not on a ragged last tile (clamped rows).
+            if (!ragged) {
+                float mx = acc[0][y][0];
+#pragma unroll
+                for (int r = 1; r < 16; ++r) mx = fmaxf(mx, acc[0][y][r]);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, acc[1][y][r]);
+                if (__ballot(qv && !(mx < thr)) == 0ull) continue;
+            }
             u64 *cq = cand + (size_t)ql * F_C;
 #pragma unroll
             for (int x = 0; x < 2; ++x)

@@ -217,3 +217,31 @@ def test_fast_path_large_query_block():
     Do, Io = search_ref.flat_ip_topk_chain(x, q[pick], 100)
     assert np.array_equal(I[pick], Io) and np.array_equal(D[pick], Do)
     assert np.all(D[:, 1:] <= D[:, :-1])
+
+
+def test_fp16_overflow_is_not_trusted():
+    """Values beyond the fp16 range (65504) break the two-precision bound; the launch must notice
+    (row / query norms) and still return the exact result."""
+    from oracle import synth
+    rng = np.random.default_rng(24)
+    x = synth.ln_rows(rng, 6000)
+    q = synth.ln_rows(rng, 40)
+    xb = x.copy()
+    xb[1234, 5] = 1.0e5      # one corpus element overflows fp16
+    xb[4321, 700] = -2.0e5
+    _check_exact("ovf_corpus", xb, q, 100)
+    qb = q.copy()
+    qb[3, 17] = 9.0e4        # one query element overflows fp16
+    _check_exact("ovf_query", x, qb, 100)
+
+
+def test_sparse_candidates_after_threshold():
+    """Many corpus tiles per query block with a planted cluster of very high scorers late in the scan:
+    exercises the max-prefilter (groups with no candidate are skipped) together with late insertions."""
+    from oracle import synth
+    rng = np.random.default_rng(25)
+    x = synth.ln_rows(rng, 40000)
+    q = synth.ln_rows(rng, 300)
+    x[39000:39050] = q[:50] * np.float32(1.5)   # late, far above every threshold, each matching one query
+    x[20000:20010] = q[100:110] * np.float32(0.9)
+    _check_exact("sparse_late", x, q, 50)
