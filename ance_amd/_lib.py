@@ -43,6 +43,8 @@ SYMBOLS = {
     "ance_topk_merge": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int,
                                        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t,
                                        ctypes.c_void_p]),
+    "ance_ip_score_rows": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int,
+                                          ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "ance_encoder_weight_bytes": (ctypes.c_size_t, [ctypes.POINTER(AnceEncoderDesc)]),
     "ance_encoder_workspace_bytes": (ctypes.c_size_t, [ctypes.POINTER(AnceEncoderDesc)]),
     "ance_encoder_create": (ctypes.c_int, [ctypes.POINTER(AnceEncoderDesc), ctypes.POINTER(ctypes.c_void_p),

@@ -414,3 +414,55 @@ extern "C" int ance_topk_merge(const float *d_parts_d, const int64_t *d_parts_i,
                        (const int *)nullptr, (const u64 *)nullptr, 0);
     return check_launch("ance_topk_merge");
 }
+
+// ---- restricted-candidate scoring (include/ance_amd.h: ance_ip_score_rows) -------------------------
+namespace ance {
+namespace {
+
+// One workgroup per query: the query row is staged in LDS, each thread walks candidates j = tid, tid +
+// 256, ... and runs the canonical chain s = fmaf(q[k], x[k], s), k ascending (the scan's arithmetic).
+__global__ void __launch_bounds__(256) score_rows_kernel(const float *x, int64_t n, const float *q, int d, const int64_t *rows,
+                                                         const int64_t *offsets, float *scores) {
+    extern __shared__ __attribute__((aligned(16))) float qs[];
+    const int64_t qi = blockIdx.x;
+    for (int k = threadIdx.x; k < d; k += 256) qs[k] = q[qi * d + k];
+    __syncthreads();
+    const int64_t j0 = offsets[qi], j1 = offsets[qi + 1];
+    for (int64_t j = j0 + threadIdx.x; j < j1; j += 256) {
+        const int64_t r = rows[j];
+        if (r < 0 || r >= n) {  // documented: an out-of-range candidate scores -inf
+            scores[j] = -INFINITY;
+            continue;
+        }
+        const float *xr = x + r * d;
+        float s = 0.0f;
+        for (int k = 0; k < d; k += 4) {
+            const f32x4 xv = *reinterpret_cast<const f32x4 *>(xr + k);
+            const f32x4 qv = *reinterpret_cast<const f32x4 *>(qs + k);
+            s = __builtin_fmaf(qv[0], xv[0], s);
+            s = __builtin_fmaf(qv[1], xv[1], s);
+            s = __builtin_fmaf(qv[2], xv[2], s);
+            s = __builtin_fmaf(qv[3], xv[3], s);
+        }
+        scores[j] = s;
+    }
+}
+
+}  // namespace
+}  // namespace ance
+
+extern "C" int ance_ip_score_rows(const float *d_x, int64_t n, const float *d_q, int64_t nq, int d, const int64_t *d_rows,
+                                  const int64_t *d_offsets, float *d_scores, void *stream) {
+    using namespace ance;
+    if (nq < 0 || n < 0 || d < 4 || d % 4 || d > 16384 || (nq > 0 && (!d_q || !d_offsets)) || (n > 0 && !d_x)) {
+        set_last_error("ance_ip_score_rows: invalid argument (d must be a multiple of 4)");
+        return ANCE_E_INVALID;
+    }
+    if (nq == 0) return ANCE_OK;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(score_rows_kernel, dim3((unsigned)nq), dim3(256), (size_t)d * sizeof(float), st, d_x, n, d_q, d, d_rows,
+                       d_offsets, d_scores);
+    int rc = check_launch("ance_ip_score_rows");
+    if (rc) return rc;
+    return ANCE_OK;
+}

@@ -90,6 +90,17 @@ size_t ance_topk_merge_workspace_bytes(int n_parts, int64_t nq, int k);
 int ance_topk_merge(const float *d_parts_d, const int64_t *d_parts_i, int n_parts, int64_t nq, int k,
                     float *d_out_d, int64_t *d_out_i, void *d_workspace, size_t workspace_bytes, void *stream);
 
+/*
+ * Restricted-candidate scoring (the rerank of evaluation/"Calculate Metrics.ipynb" cell 11 and
+ * utils/eval_mrr.py:94-105, where a per-query faiss sub-index is built from the BM25 candidates):
+ * d_scores[j] = <d_q[qi], d_x[d_rows[j]]> for d_offsets[qi] <= j < d_offsets[qi+1], with the same
+ * fp32 fmaf chain (k ascending from +0) as ance_ip_topk, so scores are bitwise those of the full scan.
+ * d_rows: int64 row ids in [0, n) (an id outside the range scores -inf); d_offsets: int64 [nq + 1]
+ * ascending, d_offsets[0] = 0.  Enqueues on `stream` and returns.
+ */
+int ance_ip_score_rows(const float *d_x, int64_t n, const float *d_q, int64_t nq, int d, const int64_t *d_rows,
+                       const int64_t *d_offsets, float *d_scores, void *stream);
+
 /* ------------------------------------------------------------------------ dual encoder ------ */
 
 #define ANCE_ARCH_ROBERTA 0 /* positions = cumsum(id != pad) * (id != pad) + pad, type 0     */

@@ -139,7 +139,9 @@ _CUTS = (5, 10, 15, 20, 30, 100, 200, 500, 1000)
 
 class RelevanceEvaluator:
     """Minimal ``pytrec_eval.RelevanceEvaluator``: trec_eval's ``ndcg_cut`` (gain = rel,
-    discount log2(rank+1), ideal from the judged rels sorted descending) and ``map_cut``.
+    discount log2(rank+1), ideal from the judged rels sorted descending), ``map_cut``, ``recall`` and
+    ``recip_rank`` (relevant = rel > 0).  pytrec_eval itself is not installable here: these four are the
+    published trec_eval definitions, unpinned at that boundary.
     Run ordering follows trec_eval: score descending, ties by doc id descending."""
 
     def __init__(self, qrel, measures):
@@ -170,6 +172,11 @@ class RelevanceEvaluator:
                             hit += 1
                             s += hit / (i + 1)
                     out["map_cut_%d" % c] = s / num_rel if num_rel > 0 else 0.0
+                if "recall" in self.measures:
+                    out["recall_%d" % c] = sum(1 for g in gains[:c] if g > 0) / num_rel if num_rel > 0 else 0.0
+            if "recip_rank" in self.measures:
+                first = next((i for i, g in enumerate(gains) if g > 0), None)
+                out["recip_rank"] = 1.0 / (first + 1) if first is not None else 0.0
             res[qid] = out
         return res
 

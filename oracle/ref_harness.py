@@ -155,3 +155,23 @@ def run_reference_preprocess(data_dir, out_data_dir, data_type, tokenizer_cls, m
         ref.msmarco_data.preprocess(args)
     finally:
         cfg.tokenizer_class = old
+
+
+def notebook_eval_dev_query():
+    """The ``EvalDevQuery`` of evaluation/"Calculate Metrics.ipynb" (cell 8) as a callable: the cell's own
+    source executed with the reference's utils/msmarco_eval.compute_metrics (real code) and
+    oracle.ann_ref.RelevanceEvaluator standing in for pytrec_eval."""
+    import json
+    ref = load_reference()  # noqa: F841  (sys.path for utils.*)
+    from oracle import ann_ref
+    msmarco_eval = importlib.import_module("utils.msmarco_eval")
+    with open(os.path.join(REF_ROOT, "evaluation", "Calculate Metrics.ipynb")) as f:
+        nb = json.load(f)
+    src = None
+    for c in nb["cells"]:
+        if c["cell_type"] == "code" and "def EvalDevQuery" in "".join(c["source"]):
+            src = "".join(c["source"])
+    ns = {"pytrec_eval": types.SimpleNamespace(RelevanceEvaluator=ann_ref.RelevanceEvaluator),
+          "compute_metrics": msmarco_eval.compute_metrics}
+    exec(compile(src, "Calculate Metrics.ipynb#cell8", "exec"), ns)
+    return ns["EvalDevQuery"]

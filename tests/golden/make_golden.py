@@ -215,10 +215,37 @@ def golden_preprocess():
     return {k: len(v) for k, v in out.items()}
 
 
+def golden_metrics():
+    """evaluation/"Calculate Metrics.ipynb" cell 8 (EvalDevQuery) on seeded neighbour lists: a MaxP-style
+    row -> pid map, graded judgements incl. rel 0, unjudged holes, queries without any relevant hit."""
+    E = ref_harness.notebook_eval_dev_query()
+    rng = np.random.default_rng(3)
+    n_rows, chunks, nq = 3000, 3, 40
+    p2id = (np.arange(n_rows) // chunks).astype(np.int64)
+    q2id = np.arange(nq, dtype=np.int64)
+    I = np.stack([rng.choice(n_rows, size=150, replace=False) for _ in range(nq)])
+    qrels = {}
+    for i in range(nq + 5):  # five reference queries are never ranked (they count in the MS MARCO MRR denominator)
+        d = {}
+        for j in rng.choice(160, size=int(rng.integers(1, 5)), replace=False):
+            pid = int(p2id[I[i % nq, j]]) if j < 150 else int(rng.integers(0, n_rows // chunks))
+            d[pid] = int(rng.integers(0, 4))
+        qrels[i] = d
+    out = {}
+    for topN in (100, 1000):
+        r = E(q2id, p2id, qrels, I, topN)
+        out[str(topN)] = dict(ndcg=r[0], queries=r[1], map=r[2], mrr=r[3], recall=r[4], hole_rate=r[5], ms_mrr=r[6],
+                              ahole_rate=r[7])
+    np.savez_compressed(os.path.join(OUT, "metrics.npz"), p2id=p2id, q2id=q2id, I=I)
+    with open(os.path.join(OUT, "metrics.json"), "w") as f:
+        json.dump(dict(qrels={str(a): {str(b): c for b, c in d.items()} for a, d in qrels.items()}, results=out), f)
+    return {k: v["ndcg"] for k, v in out.items()}
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     info = dict(encoder=golden_encoder(), postsearch=golden_postsearch(), e2e=golden_end_to_end(), dpr=golden_dpr(),
-                preprocess=golden_preprocess(),
+                preprocess=golden_preprocess(), metrics=golden_metrics(),
                 torch=torch.__version__, numpy=np.__version__)
     with open(os.path.join(OUT, "manifest.json"), "w") as f:
         json.dump(info, f, indent=1)
