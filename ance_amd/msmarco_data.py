@@ -96,7 +96,11 @@ def _tokenize_splits(job):
     """One worker: lines ``idx`` with ``idx % N_SPLITS`` in ``splits`` -> ``{out_path}_split{idx % N_SPLITS}``."""
     args, splits, in_path, out_path, fn_name = job
     tokenizer = load_tokenizer(args)
-    line_fn = PassagePreprocessingFn if fn_name == "passage" else QueryPreprocessingFn
+    if isinstance(fn_name, tuple):  # (module, function): other producers (ance_amd.dpr_data) reuse the split engine
+        import importlib
+        line_fn = getattr(importlib.import_module(fn_name[0]), fn_name[1])
+    else:
+        line_fn = PassagePreprocessingFn if fn_name == "passage" else QueryPreprocessingFn
     outs = {s: open("{}_split{}".format(out_path, s), "wb") for s in splits}
     try:
         with _open_text(in_path) as in_f:

@@ -175,3 +175,23 @@ def notebook_eval_dev_query():
           "compute_metrics": msmarco_eval.compute_metrics}
     exec(compile(src, "Calculate Metrics.ipynb#cell8", "exec"), ns)
     return ns["EvalDevQuery"]
+
+
+def run_reference_dpr_preprocess(wiki_dir, question_dir, answer_dir, out_data_dir, data_type, tokenizer_cls,
+                                 max_seq_length=24):
+    """Run the reference's own data/DPR_data.py ``preprocess`` with ``tokenizer_cls`` standing in for
+    bert-base-uncased (data_type 0 = NQ, 1 = TriviaQA; 2 dereferences row 58,812 of the merged training
+    queries -- data/DPR_data.py:215 -- and cannot run on small inputs)."""
+    ref = load_reference()
+    dpr_data = importlib.import_module("data.DPR_data")
+    cfg = ref.models.MSMarcoConfigDict["dpr"]
+    old = cfg.tokenizer_class
+    cfg.tokenizer_class = tokenizer_cls
+    try:
+        os.makedirs(out_data_dir, exist_ok=True)
+        args = types.SimpleNamespace(out_data_dir=out_data_dir, model_type="dpr", model_name_or_path="unused",
+                                     max_seq_length=max_seq_length, data_type=data_type, question_dir=question_dir,
+                                     wiki_dir=wiki_dir, answer_dir=answer_dir)
+        dpr_data.preprocess(args)
+    finally:
+        cfg.tokenizer_class = old

@@ -188,3 +188,78 @@ def make_raw_msmarco(data_dir, data_type, n_passages=70, n_train=25, n_dev=9, se
     else:
         queries("queries.train.tsv", "qrels.train.tsv", n_train, 500000, "\t")
         queries("queries.dev.small.tsv", "qrels.dev.small.tsv", n_dev, 900000, "\t")
+
+
+class ToyBertTokenizer:
+    """BERT-shaped counterpart of ToyTokenizer ([CLS]=101, [SEP]=102, [PAD]=0) with pair encoding and the
+    ``longest_first`` truncation transformers 2.x applied whenever ``max_length`` was given."""
+    sep_token = "[SEP]"
+    sep_token_id = 102
+    pad_token_id = 0
+
+    @classmethod
+    def from_pretrained(cls, *args, **kwargs):
+        return cls()
+
+    @staticmethod
+    def _words(text):
+        import zlib
+        return [1000 + zlib.crc32(w.lower().encode("utf8")) % 29000 for w in text.split()]
+
+    def encode(self, text, text_pair=None, add_special_tokens=True, max_length=None, **kwargs):
+        a = self._words(text)
+        b = self._words(text_pair) if text_pair is not None else None
+        if max_length is not None:
+            budget = max_length - (3 if b is not None else 2)
+            while len(a) + (len(b) if b is not None else 0) > max(budget, 0):
+                if b is not None and len(b) > len(a):
+                    b.pop()
+                elif a:
+                    a.pop()
+                else:
+                    b.pop()
+        ids = [101] + a + [102]
+        if b is not None:
+            ids += b + [102]
+        return ids
+
+
+def toy_bert_tokenizer_factory():
+    return ToyBertTokenizer()
+
+
+def make_raw_dpr(root, n_passages=90, n_nq=14, n_trivia=11, seed=9):
+    """psgs_w100.tsv (with its header row), nq/trivia train+dev json (some samples without positives or
+    without hard negatives: they must be dropped), nq/trivia test csv.  Returns (wiki_dir, question_dir, answer_dir)."""
+    import json as _json
+    rng = np.random.default_rng(seed)
+    wiki, qdir, adir = (os.path.join(root, d) for d in ("wiki", "questions", "answers"))
+    for d in (wiki, qdir, adir):
+        os.makedirs(d, exist_ok=True)
+
+    def text(lo, hi):
+        return " ".join(_WORDS[int(j)] for j in rng.integers(0, len(_WORDS), size=int(rng.integers(lo, hi))))
+
+    with open(os.path.join(wiki, "psgs_w100.tsv"), "w", encoding="utf-8") as f:
+        f.write("id\ttext\ttitle\n")
+        for p in range(1, n_passages + 1):
+            f.write('%d\t"%s"\t%s\n' % (p, text(5, 40), text(1, 4)))
+
+    def samples(n, key):
+        out = []
+        for i in range(n):
+            pos = [{key: str(int(rng.integers(1, n_passages + 1)))} for _ in range(int(rng.integers(0, 3)))]
+            neg = [{key: str(int(rng.integers(1, n_passages + 1)))} for _ in range(int(rng.integers(0, 4)))]
+            out.append({"question": text(3, 9) + ("?" if i % 2 else ""), "answers": [text(1, 3), "it's \"x\""][: 1 + i % 2],
+                        "positive_ctxs": pos, "hard_negative_ctxs": neg})
+        return out
+
+    for name, n, key in (("nq-train.json", n_nq, "passage_id"), ("trivia-train.json", n_trivia, "psg_id"),
+                         ("nq-dev.json", 6, "passage_id"), ("trivia-dev.json", 5, "psg_id")):
+        with open(os.path.join(qdir, name), "w", encoding="utf-8") as f:
+            _json.dump(samples(n, key), f)
+    for name, n in (("nq-test.csv", 7), ("trivia-test.csv", 5)):
+        with open(os.path.join(adir, name), "w", encoding="utf-8") as f:
+            for i in range(n):
+                f.write("%s%s\t['%s']\n" % (text(3, 9), "?" if i % 3 == 0 else "", text(1, 3)))
+    return wiki, qdir, adir

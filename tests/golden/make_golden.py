@@ -215,6 +215,33 @@ def golden_preprocess():
     return {k: len(v) for k, v in out.items()}
 
 
+def golden_dpr_preprocess():
+    """The reference's own data/DPR_data.py ``preprocess`` (NQ and TriviaQA layouts) on seeded raw inputs
+    with oracle.synth.ToyBertTokenizer: sha256 of every merged output."""
+    import hashlib
+    import shutil
+    import tempfile
+    out = {}
+    for data_type in (0, 1):
+        tmp = tempfile.mkdtemp(prefix="ance_golden_dpr_")
+        try:
+            wiki, qd, ad = synth.make_raw_dpr(tmp, n_passages=90, n_nq=14, n_trivia=11, seed=9)
+            dst = os.path.join(tmp, "out") + "/"
+            ref_harness.run_reference_dpr_preprocess(wiki, qd, ad, dst, data_type, synth.ToyBertTokenizer, max_seq_length=24)
+            files = {}
+            for f in sorted(os.listdir(dst)):
+                if "_split" in f:
+                    continue
+                with open(os.path.join(dst, f), "rb") as fh:
+                    files[f] = hashlib.sha256(fh.read()).hexdigest()
+            out[str(data_type)] = files
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+    with open(os.path.join(OUT, "dpr_preprocess.json"), "w") as f:
+        json.dump(dict(raw=dict(n_passages=90, n_nq=14, n_trivia=11, seed=9), max_seq_length=24, sha256=out), f, indent=1)
+    return {k: len(v) for k, v in out.items()}
+
+
 def golden_metrics():
     """evaluation/"Calculate Metrics.ipynb" cell 8 (EvalDevQuery) on seeded neighbour lists: a MaxP-style
     row -> pid map, graded judgements incl. rel 0, unjudged holes, queries without any relevant hit."""
@@ -245,7 +272,7 @@ def golden_metrics():
 if __name__ == "__main__":
     torch.set_num_threads(8)
     info = dict(encoder=golden_encoder(), postsearch=golden_postsearch(), e2e=golden_end_to_end(), dpr=golden_dpr(),
-                preprocess=golden_preprocess(), metrics=golden_metrics(),
+                preprocess=golden_preprocess(), metrics=golden_metrics(), dpr_preprocess=golden_dpr_preprocess(),
                 torch=torch.__version__, numpy=np.__version__)
     with open(os.path.join(OUT, "manifest.json"), "w") as f:
         json.dump(info, f, indent=1)
