@@ -304,38 +304,66 @@ __global__ void __launch_bounds__(F_THREADS, 2) ip_topk_fast_kernel(const FastPa
     }
     __syncthreads();
 
-    // ---- block end: exact re-scoring of every kept row, exact top-k of the split ---------------------
+    // ---- block end: final band prune, exact re-scoring of the band, exact top-k of the split -----------
+    // A buffer ends the scan with 700-1,700 rows (everything above the LAST threshold), but only the rows
+    // within 2 eps of the final k-th best approximate score (about k + 66) can be in the exact top-k.
+    // Re-scoring costs a 3 KB row read each, so the band is cut first: the k-th approximate key by the
+    // same radix select, the survivors' buffer positions compacted into an LDS list (dense: every lane
+    // re-scores one row per round), exact keys kept in registers and selected from there.
     float *qrow_lds = smem_f + w * 1024;  // 4 KiB per wave in the idle stage area (d <= 1024)
+    unsigned short *list = reinterpret_cast<unsigned short *>(smem_f + 8 * 1024) + w * F_C;  // 4 KiB per wave
+    const u64 lt_mask = (1ull << l) - 1ull;
     for (int qq = 0; qq < 32; ++qq) {
         const int ql = w * 32 + qq;
         const uint32_t qg = q0 + ql;
         if (qg >= P.nq) continue;  // wave-uniform
         const int n_c = __builtin_amdgcn_readfirstlane(cnt_s[ql]);
-        u64 *cq = cand + (size_t)ql * F_C;
+        const u64 *cq = cand + (size_t)ql * F_C;
         u64 *dst = P.part + ((size_t)qg * P.S + split) * (size_t)P.k;
         const float *qsrc = P.q32 + (size_t)qg * d;
         for (int k4 = l * 4; k4 < d; k4 += 256) *reinterpret_cast<f32x4 *>(qrow_lds + k4) = *reinterpret_cast<const f32x4 *>(qsrc + k4);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        // 64 rows at a time, one per lane; exact keys replace the approximate ones in place.  The
-        // write-back and the re-read for the selection cross lanes of this wave through global memory:
-        // write-through stores, a drained vmcnt, then L1-bypassing loads.
-        for (int e0 = 0; e0 < n_c; e0 += 64) {
-            const int e = e0 + l;
-            if (e < n_c) {
-                const uint32_t prow = key_row(cq[e]);
-                const u64 v = pack_key(exact_ip_lds(qrow_lds, P.x32 + (size_t)prow * d, d), prow);
-                __hip_atomic_store(&cq[e], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         u64 keys[F_NPL];
 #pragma unroll
         for (int j = 0; j < F_NPL; ++j) {
-            const int e = j * 64 + l;
-            keys[j] = (e < n_c) ? __hip_atomic_load(&cq[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+            const int idx = j * 64 + l;
+            keys[j] = (idx < n_c) ? cq[idx] : 0ull;
         }
+        float thr_band = -INFINITY;
         if (n_c > P.k) {
+            u64 T = 0;  // k-th largest approximate key
+            for (int bit = 63; bit >= 0; --bit) {
+                const u64 t2 = T | (1ull << bit);
+                int ge = 0;
+#pragma unroll
+                for (int j = 0; j < F_NPL; ++j) ge += __popcll(__ballot(keys[j] >= t2));
+                if (ge >= P.k) T = t2;
+            }
+            thr_band = key_score(T) - eps2_s[ql];
+        }
+        int n_band = 0;
+#pragma unroll
+        for (int j = 0; j < F_NPL; ++j) {
+            const bool keep = keys[j] != 0ull && !(key_score(keys[j]) < thr_band);
+            const u64 m = __ballot(keep);
+            if (keep) list[n_band + __popcll(m & lt_mask)] = (unsigned short)(j * 64 + l);
+            n_band += __popcll(m);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // exact keys, dense: round r, lane l re-scores list entry 64 r + l
+#pragma unroll
+        for (int j = 0; j < F_NPL; ++j) keys[j] = 0ull;
+        for (int r = 0; r * 64 < n_band; ++r) {
+            const int e = r * 64 + l;
+            u64 v = 0ull;
+            if (e < n_band) {
+                const uint32_t prow = key_row(cq[list[e]]);
+                v = pack_key(exact_ip_lds(qrow_lds, P.x32 + (size_t)prow * d, d), prow);
+            }
+#pragma unroll
+            for (int j = 0; j < F_NPL; ++j) keys[j] = (j == r) ? v : keys[j];  // r is wave-uniform: register file stays static
+        }
+        if (n_band > P.k) {
             float tau_new;
             select_topk_regs<F_NPL>(keys, P.k, dst, &tau_new);
         } else {
@@ -345,6 +373,7 @@ __global__ void __launch_bounds__(F_THREADS, 2) ip_topk_fast_kernel(const FastPa
                 if (e < P.k) dst[e] = keys[j];
             }
         }
+        __builtin_amdgcn_wave_barrier();  // the next query reuses qrow_lds and list
     }
 }
 
