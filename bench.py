@@ -208,10 +208,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist_on = world > 1
+    # one rank per GPU; ANCE_BENCH_BACKEND=gloo lets two ranks share a GPU to exercise the N > 1 code path on a
+    # one-GPU box (RCCL refuses duplicate devices) -- a functional check, not a measurement
+    backend = os.environ.get("ANCE_BENCH_BACKEND", "nccl")
+    local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if dist_on:
-        torch.distributed.init_process_group(backend="nccl", device_id=dev)
+        if backend == "nccl":
+            torch.distributed.init_process_group(backend="nccl", device_id=dev)
+        else:
+            torch.distributed.init_process_group(backend=backend)
     from ance_amd import _lib
     from ance_amd import ann_data_gen as adg
     from ance_amd.cache import shard_range
