@@ -8,11 +8,14 @@
 //   QK   = h16 Wqk^T + b          (gemm EPI_QK, Q pre-scaled by 1/8)        [T, 1536] f16
 //   V^T  = Wv h16^T + b           (gemm EPI_VT, key-contiguous)             [768, cols] f16
 //   ctx  = softmax(Q K^T) V       (attention.hip)                           [T, 768] f16
-//   pre  = ctx Wo^T + b + h32     (gemm EPI_RES32)                          [T, 768] f32
-//   h    = LayerNorm(pre)         -> h32 (residual stream, fp32) and h16 (next MFMA operand)
+//   preA = ctx Wo^T + b + LN(preB)  (gemm EPI_RES32)                        [T, 768] f32
+//   LayerNorm(preA)               -> h16 (next MFMA operand) and per-row (mean, rstd)
 //   f    = gelu(h16 W1^T + b)     (gemm EPI_GELU)                           [T, 3072] f16
-//   pre  = f W2^T + b + h32 ; h = LayerNorm(pre)
-// then  emb = LayerNorm(Wh h32[cls] + bh)  (fp32)  or raw h32[cls] for DPR's BERT.
+//   preB = f W2^T + b + LN(preA) ; LayerNorm(preB) -> h16, (mean, rstd)
+// then  emb = LayerNorm(Wh LN(preB)[cls] + bh)  (fp32)  or raw LN(preB)[cls] for DPR's BERT.
+// The fp32 residual stream h = LN(pre) is never stored: its consumers (the next RES32 epilogue, the
+// [CLS] gather, the head) recompute it from the pre-LN row and the two row statistics with the one
+// expression ln_apply4 -- 6 KB per token and layer less HBM traffic (LayerNorm kernel 72 -> ~46 us).
 // Precision: fp16 MFMA operands, fp32 accumulation, fp32 residual stream / LayerNorm / softmax.
 #include <stdlib.h>
 #include <string.h>
@@ -169,8 +172,10 @@ __global__ void __launch_bounds__(256) pack_kernel(const PlanArgs P) {
 }
 
 // LayerNorm of one 768-wide row held as 12 floats per lane (3 x float4, lane-contiguous)
+// LayerNorm of one 768-wide row held by one wave (3 float4 per lane): fp16 output for the next GEMM and the
+// row statistics for the consumers of the fp32 value (see the file header).
 __device__ __forceinline__ void ln_row_store(f32x4 v0, f32x4 v1, f32x4 v2, const float *gamma, const float *beta,
-                                             float eps, float *out32, _Float16 *out16, int l) {
+                                             float eps, _Float16 *out16, float *stats, int l) {
     float s = 0.f;
 #pragma unroll
     for (int j = 0; j < 4; ++j) s += v0[j] + v1[j] + v2[j];
@@ -192,20 +197,19 @@ __device__ __forceinline__ void ln_row_store(f32x4 v0, f32x4 v1, f32x4 v2, const
 #pragma unroll
     for (int p = 0; p < 3; ++p) {
         const int c4 = p * 64 + l;  // float4 index within the row
-        const f32x4 gg = g4[c4], bb = b4[c4];
-        f32x4 y;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) y[j] = (vin[p][j] - mean) * rstd * gg[j] + bb[j];
-        if (out32) reinterpret_cast<f32x4 *>(out32)[c4] = y;
-        if (out16) reinterpret_cast<f16x4 *>(out16)[c4] = f16x4{(_Float16)y[0], (_Float16)y[1], (_Float16)y[2], (_Float16)y[3]};
+        const f32x4 y = ln_apply4(vin[p], mean, rstd, g4[c4], b4[c4]);
+        reinterpret_cast<f16x4 *>(out16)[c4] = f16x4{(_Float16)y[0], (_Float16)y[1], (_Float16)y[2], (_Float16)y[3]};
+    }
+    if (l == 0) {
+        stats[0] = mean;
+        stats[1] = rstd;
     }
 }
 
-// embeddings (modeling_roberta.py:75-121): word[id] + type[0] + pos[p], LayerNorm
 __global__ void __launch_bounds__(256) embed_ln_kernel(const int *tok_id, const int *tok_pos, int Tpad, const float *word,
                                                        const float *pos, const float *type0, int vocab, int max_pos,
-                                                       const float *gamma, const float *beta, float eps, float *h32,
-                                                       _Float16 *h16) {
+                                                       const float *gamma, const float *beta, float eps, float *pre,
+                                                       _Float16 *h16, float *stats) {
     const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int l = threadIdx.x & 63;
     if (t >= Tpad) return;
@@ -220,50 +224,57 @@ __global__ void __launch_bounds__(256) embed_ln_kernel(const int *tok_id, const 
     for (int k = 0; k < 3; ++k) {
         const int c4 = k * 64 + l;
         v[k] = (w4[c4] + t4[c4]) + p4[c4];  // same association as the reference: (word + type) + pos
+        reinterpret_cast<f32x4 *>(pre + (size_t)t * H)[c4] = v[k];
     }
-    ln_row_store(v[0], v[1], v[2], gamma, beta, eps, h32 + (size_t)t * H, h16 + (size_t)t * H, l);
+    ln_row_store(v[0], v[1], v[2], gamma, beta, eps, h16 + (size_t)t * H, stats + 2 * (size_t)t, l);
 }
 
 __global__ void __launch_bounds__(256) ln_kernel(const float *pre, int Tpad, const float *gamma, const float *beta, float eps,
-                                                 float *h32, _Float16 *h16) {
+                                                 _Float16 *h16, float *stats) {
     const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int l = threadIdx.x & 63;
     if (t >= Tpad) return;
     const f32x4 *x4 = reinterpret_cast<const f32x4 *>(pre + (size_t)t * H);
-    ln_row_store(x4[l], x4[64 + l], x4[128 + l], gamma, beta, eps, h32 + (size_t)t * H, h16 + (size_t)t * H, l);
+    ln_row_store(x4[l], x4[64 + l], x4[128 + l], gamma, beta, eps, h16 + (size_t)t * H, stats + 2 * (size_t)t, l);
 }
 
-// last layer, CLS-only tail: compact residual rows  dst[s] = h32[seq_off[s]]  (rows S..S_pad zeroed)
-__global__ void __launch_bounds__(256) gather_cls_kernel(const float *h32, const int *seq_off, int S, int S_pad, float *dst) {
+// last layer, CLS-only tail: compact residual rows  dst[s] = LN(pre[seq_off[s]])  (rows S..S_pad zeroed)
+__global__ void __launch_bounds__(256) gather_cls_kernel(const float *pre, const float *stats, const float *gamma,
+                                                         const float *beta, const int *seq_off, int S, int S_pad, float *dst) {
     const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int l = threadIdx.x & 63;
     if (s >= S_pad) return;
     f32x4 *d4 = reinterpret_cast<f32x4 *>(dst + (size_t)s * H);
     if (s < S) {
-        const f32x4 *s4 = reinterpret_cast<const f32x4 *>(h32 + (size_t)seq_off[s] * H);
+        const size_t row = (size_t)seq_off[s];
+        const f32x4 *s4 = reinterpret_cast<const f32x4 *>(pre + row * H);
+        const float mean = stats[2 * row], rstd = stats[2 * row + 1];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) d4[k * 64 + l] = s4[k * 64 + l];
+        for (int k = 0; k < 3; ++k)
+            d4[k * 64 + l] = ln_apply4(s4[k * 64 + l], mean, rstd, reinterpret_cast<const f32x4 *>(gamma)[k * 64 + l],
+                                       reinterpret_cast<const f32x4 *>(beta)[k * 64 + l]);
     } else {
 #pragma unroll
         for (int k = 0; k < 3; ++k) d4[k * 64 + l] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 }
 
-// head: emb = LayerNorm_768(W h_cls + b) (model/models.py:152-153), or raw h_cls (models.py:239)
-__global__ void __launch_bounds__(256) head_kernel(const float *h32, const int *seq_off, int compact, const float *W,
-                                                   const float *b, const float *gamma, const float *beta, int has_head,
-                                                   float *out) {
+__global__ void __launch_bounds__(256) head_kernel(const float *pre, const float *stats, const float *lng, const float *lnb,
+                                                   const int *seq_off, int compact, const float *W, const float *b,
+                                                   const float *gamma, const float *beta, int has_head, float *out) {
     __shared__ float cls[H];
     __shared__ float z[HEAD_OUT];
     __shared__ float red[8];
     const int s = blockIdx.x, tid = threadIdx.x;
-    const float *src = h32 + (size_t)(compact ? s : seq_off[s]) * H;  // compact: row s already is the [CLS] row
+    const size_t row = (size_t)(compact ? s : seq_off[s]);  // compact: row s already is the [CLS] row
+    const float *src = pre + row * H;
+    const float mean_h = stats[2 * row], rstd_h = stats[2 * row + 1];  // h = LN(pre), recomputed (file header)
     float *dst = out + (size_t)s * HEAD_OUT;
     if (!has_head) {
-        for (int j = tid; j < H; j += 256) dst[j] = src[j];
+        for (int j = tid; j < H; j += 256) dst[j] = (src[j] - mean_h) * rstd_h * lng[j] + lnb[j];
         return;
     }
-    for (int j = tid; j < H; j += 256) cls[j] = src[j];
+    for (int j = tid; j < H; j += 256) cls[j] = (src[j] - mean_h) * rstd_h * lng[j] + lnb[j];
     __syncthreads();
     // each wave computes output features n = w, w+4, ...: lanes split k, reduce by shuffle
     const int w = tid >> 6, l = tid & 63;
@@ -333,7 +344,8 @@ struct AnceEncoder {
     int *lens_fetch;
     struct Lane {
         int *seq_off, *seq_vtcol, *seq_len, *tok_id, *tok_pos, *tok_vtcol;
-        float *h32, *pre32;
+        float *preA, *preB;      // pre-LayerNorm rows: attention block output / FFN block output (or embeddings)
+        float *statsA, *statsB;  // (mean, rstd) per row of preA / preB
         _Float16 *h16, *qk16, *vt16, *ctx16, *ffn16;
     } lane[2];
     int n_lanes;
@@ -399,7 +411,8 @@ void layout_workspace(const AnceEncoderDesc *d, Arena &a, AnceEncoder *e) {
         AnceEncoder::Lane L;
         L.seq_off = a.take<int>(scap + 1); L.seq_vtcol = a.take<int>(scap); L.seq_len = a.take<int>(scap);
         L.tok_id = a.take<int>(tcap); L.tok_pos = a.take<int>(tcap); L.tok_vtcol = a.take<int>(tcap);
-        L.h32 = a.take<float>((size_t)tcap * H); L.pre32 = a.take<float>((size_t)tcap * H);
+        L.preB = a.take<float>((size_t)tcap * H); L.preA = a.take<float>((size_t)tcap * H);
+        L.statsA = a.take<float>((size_t)tcap * 2); L.statsB = a.take<float>((size_t)tcap * 2);
         L.h16 = a.take<_Float16>((size_t)tcap * H);
         L.qk16 = a.take<_Float16>((size_t)tcap * 2 * H);
         L.vt16 = a.take<_Float16>((size_t)H * vcap);
@@ -499,7 +512,7 @@ int encode_impl(AnceEncoder *e, const int32_t *base, int64_t ld, const int32_t *
             {
             ProfScope pe(PC_EMBED, st);
             hipLaunchKernelGGL(embed_ln_kernel, dim3(Tpad / 4), dim3(256), 0, st, LN.tok_id, LN.tok_pos, Tpad, e->word, e->pos,
-                               e->type0, D.vocab_size, D.max_position, e->eln_w, e->eln_b, D.ln_eps, LN.h32, LN.h16);
+                               e->type0, D.vocab_size, D.max_position, e->eln_w, e->eln_b, D.ln_eps, LN.preB, LN.h16, LN.statsB);
             }
             // Only the [CLS] row of the last layer reaches the head (model/models.py:49,152): after the
             // last layer's K / V projections everything runs on the S compact [CLS] rows.
@@ -538,17 +551,21 @@ int encode_impl(AnceEncoder *e, const int32_t *base, int64_t ld, const int32_t *
                     rc = launch_attention(A, S, maxlen, st);
                 }
                 if (rc) return rc;
-                // attention.output.dense + residual
-                const float *resid = LN.h32;
-                if (tail) {  // compact residual rows, parked in the (currently dead) FFN buffer
+                // attention.output.dense + residual.  The residual is LN(preB) with the LayerNorm that produced
+                // this layer's input: the previous layer's output.LayerNorm, or the embedding LayerNorm.
+                const float *rg = li == 0 ? e->eln_w : e->layers[li - 1].ln2w;
+                const float *rb = li == 0 ? e->eln_b : e->layers[li - 1].ln2b;
+                memset(&G, 0, sizeof(G));
+                G.res32 = LN.preB; G.res_stats = LN.statsB; G.res_gamma = rg; G.res_beta = rb;
+                if (tail) {  // compact residual rows (already normalised), parked in the (currently dead) FFN buffer
                     float *rc = reinterpret_cast<float *>(LN.ffn16);
                     ProfScope ps(PC_LN, st);
-                    hipLaunchKernelGGL(gather_cls_kernel, dim3(S_pad / 4), dim3(256), 0, st, LN.h32, LN.seq_off, S, S_pad, rc);
-                    resid = rc;
+                    hipLaunchKernelGGL(gather_cls_kernel, dim3(S_pad / 4), dim3(256), 0, st, LN.preB, LN.statsB, rg, rb, LN.seq_off,
+                                       S, S_pad, rc);
+                    G.res32 = rc; G.res_stats = nullptr;
                 }
-                memset(&G, 0, sizeof(G));
                 G.A = LN.ctx16; G.lda = H; G.B = W.wo; G.ldb = H; G.M = Mrows; G.N = H; G.K = H;
-                G.bias = W.bo; G.out32 = LN.pre32; G.res32 = resid; G.ldc = H;
+                G.bias = W.bo; G.out32 = LN.preA; G.ldc = H;
                 {
                     ProfScope ps(PC_GEMM_OUT, st, 2.0 * Mwork * (double)H * H);
                     rc = launch_gemm_f16(EPI_RES32, G, st);
@@ -556,8 +573,8 @@ int encode_impl(AnceEncoder *e, const int32_t *base, int64_t ld, const int32_t *
                 if (rc) return rc;
                 {
                     ProfScope ps(PC_LN, st);
-                    hipLaunchKernelGGL(ln_kernel, dim3(Mrows / 4), dim3(256), 0, st, LN.pre32, Mrows, W.ln1w, W.ln1b, D.ln_eps,
-                                       LN.h32, LN.h16);
+                    hipLaunchKernelGGL(ln_kernel, dim3(Mrows / 4), dim3(256), 0, st, LN.preA, Mrows, W.ln1w, W.ln1b, D.ln_eps,
+                                       LN.h16, LN.statsA);
                 }
                 // intermediate.dense + GELU
                 memset(&G, 0, sizeof(G));
@@ -571,7 +588,8 @@ int encode_impl(AnceEncoder *e, const int32_t *base, int64_t ld, const int32_t *
                 // output.dense + residual
                 memset(&G, 0, sizeof(G));
                 G.A = LN.ffn16; G.lda = I; G.B = W.w2; G.ldb = I; G.M = Mrows; G.N = H; G.K = I;
-                G.bias = W.b2; G.out32 = LN.pre32; G.res32 = LN.h32; G.ldc = H;
+                G.bias = W.b2; G.out32 = LN.preB; G.ldc = H;
+                G.res32 = LN.preA; G.res_stats = LN.statsA; G.res_gamma = W.ln1w; G.res_beta = W.ln1b;
                 {
                     ProfScope ps(PC_GEMM_FFN2, st, 2.0 * Mwork * (double)I * H);
                     rc = launch_gemm_f16(EPI_RES32, G, st);
@@ -579,13 +597,15 @@ int encode_impl(AnceEncoder *e, const int32_t *base, int64_t ld, const int32_t *
                 if (rc) return rc;
                 {
                     ProfScope ps(PC_LN, st);
-                    hipLaunchKernelGGL(ln_kernel, dim3(Mrows / 4), dim3(256), 0, st, LN.pre32, Mrows, W.ln2w, W.ln2b, D.ln_eps,
-                                       LN.h32, LN.h16);
+                    hipLaunchKernelGGL(ln_kernel, dim3(Mrows / 4), dim3(256), 0, st, LN.preB, Mrows, W.ln2w, W.ln2b, D.ln_eps,
+                                       LN.h16, LN.statsB);
                 }
             }
             {
                 ProfScope ps(PC_HEAD, st);
-                hipLaunchKernelGGL(head_kernel, dim3(S), dim3(256), 0, st, LN.h32, LN.seq_off, cls_tail ? 1 : 0, e->head_w, e->head_b,
+                const LayerW &WL = e->layers[D.n_layers - 1];
+                hipLaunchKernelGGL(head_kernel, dim3(S), dim3(256), 0, st, LN.preB, LN.statsB, WL.ln2w, WL.ln2b, LN.seq_off,
+                                   cls_tail ? 1 : 0, e->head_w, e->head_b,
                                    e->norm_w, e->norm_b, D.has_head, d_out + (size_t)(r0 * n_chunks + gs) * HEAD_OUT);
             }
             gs = g;

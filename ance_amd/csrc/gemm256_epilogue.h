@@ -79,14 +79,30 @@ __device__ __forceinline__ void gemm256_epilogue(const GemmArgs &G, f32x16 (&acc
         constexpr int LS = 68;
         const int c4 = l & 15;
         const f32x4 bias = *reinterpret_cast<const f32x4 *>(G.bias + nw0 + c4 * 4);
+        const bool lazy_ln = G.res_stats != nullptr;  // uniform: residual = LayerNorm(res32 row) recomputed here
+        f32x4 lng = {0, 0, 0, 0}, lnb = {0, 0, 0, 0};
+        if (lazy_ln) {
+            lng = *reinterpret_cast<const f32x4 *>(G.res_gamma + nw0 + c4 * 4);
+            lnb = *reinterpret_cast<const f32x4 *>(G.res_beta + nw0 + c4 * 4);
+        }
 #pragma unroll
         for (int y = 0; y < 4; ++y) {
             // residual rows of this pass: issued first so their latency hides behind the LDS round trip
             f32x4 res[8];
+            float mean[8], rstd[8];
 #pragma unroll
             for (int it = 0; it < 8; ++it) {
                 const int rr = it * 4 + (l >> 4);
-                res[it] = *reinterpret_cast<const f32x4 *>(G.res32 + (size_t)(mw0 + y * 32 + rr) * G.ldc + nw0 + c4 * 4);
+                const size_t row = (size_t)(mw0 + y * 32 + rr);
+                res[it] = *reinterpret_cast<const f32x4 *>(G.res32 + row * G.ldc + nw0 + c4 * 4);
+                if (lazy_ln) {
+                    mean[it] = G.res_stats[2 * row];
+                    rstd[it] = G.res_stats[2 * row + 1];
+                }
+            }
+            if (lazy_ln) {
+#pragma unroll
+                for (int it = 0; it < 8; ++it) res[it] = ln_apply4(res[it], mean[it], rstd[it], lng, lnb);
             }
             __syncthreads();
 #pragma unroll

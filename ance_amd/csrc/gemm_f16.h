@@ -15,6 +15,10 @@ struct GemmArgs {
     _Float16 *out16;
     float *out32;
     const float *res32;  // EPI_RES32: residual, same layout as out32
+    // EPI_RES32, optional: the residual is LayerNorm(res32) and is recomputed here from the pre-LN rows and the
+    // per-row (mean, rstd) the LayerNorm kernel left -- the normalised fp32 rows are never written to HBM.
+    const float *res_stats;  // [M][2] or null (res32 is then used as it is)
+    const float *res_gamma, *res_beta;  // [N]
     int ldc;             // row stride of out16 / out32 / res32 (elements)
     float scale;         // EPI_QK: applied to columns n < scale_cols
     int scale_cols;
@@ -22,6 +26,15 @@ struct GemmArgs {
     int n_valid;         // EPI_VT: columns n >= n_valid are not stored
     int debug_mode;      // ance_debug_gemm ablations: 1 = no loads after tile 0, 2 = no MFMA, 4 = all blocks load tile (0,0)
 };
+
+// y = (x - mean) * rstd * gamma + beta -- the ONE expression every LayerNorm consumer uses, so that the fp32
+// residual recomputed in a GEMM epilogue is bitwise the value the LayerNorm kernel rounded to fp16.
+__device__ __forceinline__ f32x4 ln_apply4(f32x4 x, float mean, float rstd, f32x4 g, f32x4 b) {
+    f32x4 y;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) y[j] = (x[j] - mean) * rstd * g[j] + b[j];
+    return y;
+}
 
 // 256 x 256 x 64 tile kernel of gemm256_f16.hip (M, N multiples of 256, K of 64).
 int launch_gemm_f16(int epi, const GemmArgs &args, hipStream_t stream);
