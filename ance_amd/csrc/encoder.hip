@@ -32,6 +32,7 @@ constexpr int H = 768;          // hidden size this build is specialised for
 constexpr int HEAD_OUT = 768;   // embeddingHead output (model/models.py:145)
 constexpr int S_CAP_MAX = 8192; // sequences per micro-batch
 constexpr int FETCH_CHUNK = 262144;
+constexpr int MAX_LANES = 3;     // activation sets / internal streams (ANCE_ENCODER_STREAMS=1..3 selects how many are used)
 
 // ------------------------------------------------------------------------------------ kernels --
 
@@ -347,10 +348,10 @@ struct AnceEncoder {
         float *preA, *preB;      // pre-LayerNorm rows: attention block output / FFN block output (or embeddings)
         float *statsA, *statsB;  // (mean, rstd) per row of preA / preB
         _Float16 *h16, *qk16, *vt16, *ctx16, *ffn16;
-    } lane[2];
+    } lane[MAX_LANES];
     int n_lanes;
-    hipStream_t side[2];
-    hipEvent_t ev_fork, ev_join[2];
+    hipStream_t side[MAX_LANES];
+    hipEvent_t ev_fork, ev_join[MAX_LANES];
     std::vector<int32_t> host_lens;
     bool cls_tail;  // run the last layer's post-attention part on the [CLS] rows only (ANCE_CLS_TAIL=0 disables)
 };
@@ -407,7 +408,7 @@ void layout_workspace(const AnceEncoderDesc *d, Arena &a, AnceEncoder *e) {
     if (e) {
         e->tcap = tcap; e->scap = scap; e->vcap = vcap; e->lens_fetch = lens_fetch;
     }
-    for (int ln = 0; ln < 2; ++ln) {
+    for (int ln = 0; ln < MAX_LANES; ++ln) {
         AnceEncoder::Lane L;
         L.seq_off = a.take<int>(scap + 1); L.seq_vtcol = a.take<int>(scap); L.seq_len = a.take<int>(scap);
         L.tok_id = a.take<int>(tcap); L.tok_pos = a.take<int>(tcap); L.tok_vtcol = a.take<int>(tcap);
@@ -668,16 +669,16 @@ extern "C" int ance_encoder_create(const AnceEncoderDesc *desc, const void *cons
         const char *ct = getenv("ANCE_CLS_TAIL");
         e->cls_tail = !(ct && ct[0] == '0');
         const char *ns = getenv("ANCE_ENCODER_STREAMS");
-        e->n_lanes = (ns && ns[0] == '1') ? 1 : 2;
+        e->n_lanes = (ns && ns[0] >= '1' && ns[0] <= '0' + MAX_LANES) ? ns[0] - '0' : 2;
     }
-    for (int ln = 0; ln < 2; ++ln) {
+    for (int ln = 0; ln < MAX_LANES; ++ln) {
         e->side[ln] = nullptr;
         e->ev_join[ln] = nullptr;
     }
     e->ev_fork = nullptr;
     if (e->n_lanes > 1) {
         bool ok = hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) == hipSuccess;
-        for (int ln = 0; ln < 2 && ok; ++ln)
+        for (int ln = 0; ln < e->n_lanes && ok; ++ln)
             ok = hipStreamCreateWithFlags(&e->side[ln], hipStreamNonBlocking) == hipSuccess &&
                  hipEventCreateWithFlags(&e->ev_join[ln], hipEventDisableTiming) == hipSuccess;
         if (!ok) {
@@ -737,7 +738,7 @@ extern "C" int ance_encoder_create(const AnceEncoderDesc *desc, const void *cons
 
 extern "C" void ance_encoder_destroy(AnceEncoder *enc) {
     if (!enc) return;
-    for (int ln = 0; ln < 2; ++ln) {
+    for (int ln = 0; ln < MAX_LANES; ++ln) {
         if (enc->side[ln]) {
             (void)hipStreamSynchronize(enc->side[ln]);
             (void)hipStreamDestroy(enc->side[ln]);
