@@ -1,4 +1,4 @@
-// Shared epilogue of the 256 x 256 fp16 GEMM kernels (gemm256_f16.hip, gemm256r_f16.hip).
+// Epilogues of the 256 x 256 fp16 GEMM kernel (gemm256_f16.hip).
 // Swapped MFMA orientation: acc[x][y][r] holds  n = n0 + wn*64 + x*32 + (r&3) + 8*(r>>2) + 4*g,
 // m = m0 + wm*128 + y*32 + i  -- a lane owns one output row m and 4 consecutive n per register
 // quad, staged through a wave-private 16 KiB LDS slab so that global traffic is whole 16-byte row
@@ -14,8 +14,8 @@ namespace ance {
 // the error is multiplied with); beyond 5 q keeps falling, so h underflows to 0 as it should.
 // |GELU error| <= 8e-6 over [-9, 9] in fp32 (the stored result is fp16: 2^-11 relative), checked
 // against scipy's erf when the coefficients were fitted.  One transcendental (v_exp_f32) and, on four
-// adjacent columns at a time, 8 packed-fp32 ops per pair -- the A-S 7.1.26 rational form this
-// replaces needed v_rcp + v_exp + 17 scalar ops per element, and this epilogue runs on 3072 columns
+// adjacent columns at a time, packed bias add and final multiply-subtract -- the erfc rational form
+// (Abramowitz-Stegun 7.1.26) this replaces needed v_rcp + v_exp + 17 scalar ops per element, and this epilogue runs on 3072 columns
 // per token with no MFMA work to hide behind (one workgroup per CU).
 __device__ __forceinline__ f32x4 gelu_erf256(f32x4 x) {
     const f32x4 ax = __builtin_elementwise_abs(x);

@@ -9,8 +9,9 @@
 //
 // Why this tile: a 128 x 128 tile has 64 FLOP per staged byte, i.e. 39 TB/s of L2 traffic at the
 // 2.5 PFLOP/s MFMA rate -- more than the 34.5 TB/s the eight L2s deliver -- so it is L2-bound by
-// construction.  256 x 256 halves that.  8 waves (2 per SIMD), one workgroup per CU, 2 x 64 KiB LDS
-// stages, one barrier per K-tile.
+// construction.  256 x 256 halves that.  8 waves (2 per SIMD), one workgroup per CU, 128 KiB of LDS.
+// The main loop is the ping-pong pipeline of pipe256.h (half-tile staging with counted vmcnt, the
+// two waves of a SIMD alternating between LDS reads and MFMAs).
 //
 // MFMA orientation is SWAPPED with respect to the output: MFMA rows (A operand) are B-matrix rows
 // n, MFMA columns (B operand) are A-matrix rows m.  In the C-layout a lane then owns one output
@@ -19,11 +20,11 @@
 // (and the residual read) are full-width and coalesced instead of 4-byte scalars.
 //
 // Staging is direct-to-LDS (global_load_lds_dwordx4): the LDS image is lane-linear, so the XOR
-// swizzle is applied to the per-lane SOURCE address.  Measured alternatives on MI355X (DESIGN.md
-// section 9): register staging -8%, a 4-slot BK=32 ring with counted vmcnt -4..-8%, staggering the
-// two waves of a SIMD -1..-3%, a depth-2 register pipeline spills (acc 128 + 2 x 32 staging VGPRs).
-// Template ABLATE compiles the ablation switches of ance_debug_gemm in (1: no loads after the first
-// tile, 2: no MFMA, 4: every block loads tile (0,0)); the product instance has none of them.
+// swizzle is applied to the per-lane SOURCE address.  Measured alternatives on MI355X are listed in
+// DESIGN.md section 9 (register staging, a BK=32 ring, LDS-DMA placements, staggered starts, ...).
+// Template ABLATE compiles the measurement switches of ance_debug_gemm in (the two-phase loop the
+// pipeline replaced, with or without loads / MFMA; the pipeline's own ablations); the product
+// instance has none of them.
 #include "common.h"
 #include "gemm_f16.h"
 #include "gemm256_epilogue.h"
