@@ -53,3 +53,17 @@ def test_bad_shapes_are_rejected():
     assert L.ance_debug_gemm(0, 0, p, p, 128, 256, 64, p, p, None, _lib.current_stream_ptr()) == -1
     assert L.ance_debug_gemm(0, 5, p, p, 256, 256, 128, p, p, None, _lib.current_stream_ptr()) == -1
     assert L.ance_debug_gemm(0, 0, p, p, 256, 256, 64, p, p, None, _lib.current_stream_ptr()) == -1  # needs >= 2 K-tiles
+
+
+@pytest.mark.parametrize("epi", [0, 2])
+def test_full_chip_shape_repeated(epi):
+    """Race screen for the ping-pong main loop (counted vmcnt, LDS-DMA in flight across barriers): the
+    encoder's largest shapes (every CU busy, several rounds), five launches each, every element checked."""
+    M, N, K = (16384, 3072, 768) if epi == 0 else (16384, 768, 3072)
+    for rep in range(5):
+        out, ref = _run(epi, M, N, K, seed=100 + rep)
+        err = (out - ref).abs()
+        tol = 2e-3 * ref.abs() + 2e-2 if epi != 2 else 1e-3 * ref.abs() + 4e-3
+        bad = err > tol
+        assert not bad.any(), "epi %d rep %d: %d bad, max err %.4g at %s" % (
+            epi, rep, int(bad.sum()), float(err.max()), torch.nonzero(bad)[:3].tolist())
