@@ -166,7 +166,7 @@ __global__ void __launch_bounds__(G256_THREADS, 2) gemm256_f16_kernel(const Gemm
 #pragma unroll
         for (int y = 0; y < 4; ++y) acc[x][y] = f32x16{0};
 
-    if (!ABLATE || (G.debug_mode & 16)) {
+    if (!ABLATE || (G.debug_mode & (16 | 32))) {
         // product path: ping-pong pipeline of pipe256.h (debug_mode 16 + bits: its ablations)
         Pipe256T<PipeSrcFixed, ABLATE, true> P;
         P.init(smem, w, l);
@@ -181,6 +181,26 @@ __global__ void __launch_bounds__(G256_THREADS, 2) gemm256_f16_kernel(const Gemm
                 P.S.src[h][j] = G.A + (size_t)(m0 + pipe_a_tile_row(h, r)) * G.lda + ch;
                 P.S.src[2 + h][j] = G.B + (size_t)(n0 + pipe_b_tile_row(h, r)) * G.ldb + ch;
             }
+        if (ABLATE && (G.debug_mode & 32)) {
+            // timeline mode (epi 0 / 1 only): 100 MHz real-time stamps of this workgroup's phases go to the
+            // otherwise unused res32 buffer as uint64[workgroup][5]: start, prologue done, main loop done,
+            // epilogue issued, stores drained
+            unsigned long long *ts = reinterpret_cast<unsigned long long *>(const_cast<float *>(G.res32)) + (size_t)b * 5;
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+            P.prologue();
+            const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
+            P.enter();
+            P.tiles_final(G.K / TK, acc);
+            P.leave();
+            const unsigned long long t2 = __builtin_amdgcn_s_memrealtime();
+            gemm256_epilogue<EPI>(G, acc, smem_f, m0_, n0_, w, l);
+            const unsigned long long t3 = __builtin_amdgcn_s_memrealtime();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            const unsigned long long t4 = __builtin_amdgcn_s_memrealtime();
+            if (tid == 0) { ts[0] = t0; ts[1] = t1; ts[2] = t2; ts[3] = t3; ts[4] = t4; }
+            return;
+        }
         P.run(G.K / TK, acc);
     } else {
         two_phase_loop(G, acc, smem, m0_, n0_, w, l);
@@ -243,6 +263,13 @@ extern "C" int ance_debug_gemm(int ablate, int epi, const void *d_a_f16, const v
     G.debug_mode = ablate;
     if (epi == EPI_RES32) { G.out32 = (float *)d_out; G.res32 = d_res32; }
     else G.out16 = (_Float16 *)d_out;
+    if (epi != EPI_RES32 && (ablate & 32)) {  // timeline buffer
+        if (!d_res32) {
+            set_last_error("ance_debug_gemm: timeline mode needs d_res32 (uint64[M/256 * N/256][5])");
+            return ANCE_E_INVALID;
+        }
+        G.res32 = d_res32;
+    }
     ProfScope ps(PC_GEMM_FFN1, (hipStream_t)stream, 2.0 * M * (double)N * K);
     int rc = launch_gemm_f16(epi, G, (hipStream_t)stream);
     return rc ? rc : check_launch("ance_debug_gemm");

@@ -183,6 +183,8 @@ int ance_encode_ids(AnceEncoder *enc, const int32_t *d_ids, int64_t ld_ids, cons
  *   loads after the first K-tile, 2 = no MFMA, 4 = every block loads tile (0,0); 8 = no ablation
  *   (correct results; the A/B reference for the main loop).  16 + bits: the ping-pong loop with
  *   ablations 1 = every K-tile re-reads tiles 0/1, 2 = no MFMA, 4 = tile (0,0), 8 = no staging at all.
+ *   32 (epi 0 / 1): timeline -- correct results, and d_res32 receives uint64[M/256 * N/256][5] stamps of the
+ *   100 MHz real-time counter per workgroup: start, prologue done, main loop done, epilogue issued, stores drained.
  */
 int ance_debug_gemm(int ablate, int epi, const void *d_a_f16, const void *d_b_f16, int M, int N, int K,
                     const float *d_bias, void *d_out, const float *d_res32, void *stream);

@@ -184,7 +184,7 @@ static int run_gemm(int variant, int epi, int M, int N, int K, int reps) {
     CK(hipMalloc(&db, b.size() * 2)); CK(hipMemcpy(db, b.data(), b.size() * 2, hipMemcpyHostToDevice));
     CK(hipMalloc(&dbias, (size_t)N * 4)); CK(hipMemset(dbias, 0, (size_t)N * 4));
     CK(hipMalloc(&dout, (size_t)M * N * 4));
-    if (epi == 2) { CK(hipMalloc(&dres, (size_t)M * N * 4)); CK(hipMemset(dres, 0, (size_t)M * N * 4)); }
+    if (epi == 2 || (variant & 32)) { CK(hipMalloc(&dres, (size_t)M * N * 4)); CK(hipMemset(dres, 0, (size_t)M * N * 4)); }
     hipStream_t st;
     CK(hipStreamCreate(&st));
     AK(ance_debug_gemm(variant, epi, da, db, M, N, K, dbias, dout, dres, st));
@@ -200,6 +200,25 @@ static int run_gemm(int variant, int epi, int M, int N, int K, int reps) {
     const double us = 1e3 * ms / reps;
     printf("{\"probe\":\"gemm\",\"ablate\":%d,\"epi\":%d,\"M\":%d,\"N\":%d,\"K\":%d,\"us\":%.1f,\"tflops\":%.1f}\n", variant, epi, M,
            N, K, us, 2.0 * M * N * K / us / 1e6);
+    if ((variant & 32) && epi != 2) {  // timeline mode: per-workgroup phase stamps (100 MHz)
+        const int nb = (M / 256) * (N / 256);
+        std::vector<unsigned long long> ts((size_t)nb * 5);
+        CK(hipMemcpy(ts.data(), dres, ts.size() * 8, hipMemcpyDeviceToHost));
+        double ph[4] = {0, 0, 0, 0};
+        unsigned long long tmin = ~0ull, tmax = 0;
+        int cnt = 0;
+        for (int i = 0; i < nb; ++i) {
+            const unsigned long long *t = &ts[(size_t)i * 5];
+            if (!t[0]) continue;
+            for (int j = 0; j < 4; ++j) ph[j] += (double)(t[j + 1] - t[j]);
+            if (t[0] < tmin) tmin = t[0];
+            if (t[4] > tmax) tmax = t[4];
+            ++cnt;
+        }
+        printf("{\"probe\":\"gemm_timeline\",\"workgroups\":%d,\"prologue_us\":%.2f,\"main_loop_us\":%.2f,\"epilogue_issue_us\":%.2f,"
+               "\"store_drain_us\":%.2f,\"kernel_span_us\":%.1f}\n", cnt, ph[0] / cnt / 100.0, ph[1] / cnt / 100.0, ph[2] / cnt / 100.0,
+               ph[3] / cnt / 100.0, (double)(tmax - tmin) / 100.0);
+    }
     hipFree(da); hipFree(db); hipFree(dbias); hipFree(dout); if (dres) hipFree(dres);
     return 0;
 }
