@@ -17,18 +17,31 @@ namespace ance {
 // adjacent columns at a time, packed bias add and final multiply-subtract -- the erfc rational form
 // (Abramowitz-Stegun 7.1.26) this replaces needed v_rcp + v_exp + 17 scalar ops per element, and this epilogue runs on 3072 columns
 // per token with no MFMA work to hide behind (one workgroup per CU).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// coefficients live in constant memory (scalar loads) rather than as instruction literals: with literals hipcc
+// emits one v_fmaak_f32 per element, with register operands the Horner steps become v_pk_fma_f32 (two elements
+// per issue slot)
+__constant__ float kGeluQ[6] = {-1.00054646f, -1.62252474f, -0.934321642f, -0.129834279f, 0.0201726463f, -0.00133047544f};
+
 __device__ __forceinline__ f32x4 gelu_erf256(f32x4 x) {
     const f32x4 ax = __builtin_elementwise_abs(x);
-    const f32x4 z = ax * 0.70710678118654752440f;
-    f32x4 q = z * -0.00133047544f + 0.0201726463f;
-    q = q * z + -0.129834279f;
-    q = q * z + -0.934321642f;
-    q = q * z + -1.62252474f;
-    q = q * z + -1.00054646f;
-    f32x4 h;
+    f32x4 out;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) h[e] = __builtin_amdgcn_exp2f(q[e]);
-    return __builtin_elementwise_max(x, f32x4{0.0f, 0.0f, 0.0f, 0.0f}) - ax * h;
+    for (int p = 0; p < 2; ++p) {
+        const f32x2 a2 = {ax[2 * p], ax[2 * p + 1]};
+        const f32x2 z = a2 * 0.70710678118654752440f;
+        f32x2 q = z * kGeluQ[5] + kGeluQ[4];
+        q = q * z + kGeluQ[3];
+        q = q * z + kGeluQ[2];
+        q = q * z + kGeluQ[1];
+        q = q * z + kGeluQ[0];
+        const f32x2 h = {__builtin_amdgcn_exp2f(q[0]), __builtin_amdgcn_exp2f(q[1])};
+        const f32x2 x2 = {x[2 * p], x[2 * p + 1]};
+        const f32x2 r = __builtin_elementwise_max(x2, f32x2{0.0f, 0.0f}) - a2 * h;
+        out[2 * p] = r[0];
+        out[2 * p + 1] = r[1];
+    }
+    return out;
 }
 
 template <int EPI>
