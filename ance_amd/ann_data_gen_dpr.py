@@ -71,7 +71,7 @@ def load_data(args):
 
 
 def generate_new_ann(args, output_num, checkpoint_path, preloaded_data, latest_step_num, engine=None, model=None,
-                     dist=None):
+                     dist=None, pool=None):
     dist = dist or adg.Dist()
     if engine is None:
         engine = adg.HipEngine(getattr(args, "device", None))
@@ -108,10 +108,11 @@ def generate_new_ann(args, output_num, checkpoint_path, preloaded_data, latest_s
         dev_I, triv_I, I = engine.to_numpy(dev_I), engine.to_numpy(triv_I), engine.to_numpy(I)
         p2id = np.arange(n_rows, dtype=np.int64)
         matcher = dpr.AnswerMatcher(passage_text)
-        top_k_hits = dpr.validate(matcher, test_answers, dev_I, np.arange(n_dq), p2id)
-        top_k_hits_trivia = dpr.validate(matcher, trivia_answers, triv_I, np.arange(n_tq), p2id)
+        top_k_hits = dpr.validate(matcher, test_answers, dev_I, np.arange(n_dq), p2id, pool=pool)
+        top_k_hits_trivia = dpr.validate(matcher, trivia_answers, triv_I, np.arange(n_tq), p2id, pool=pool)
         q2id = np.arange(n_q, dtype=np.int64)
-        neg = dpr.generate_negative_passage_ids(matcher, train_answers, q2id, p2id, I, train_pos_id, args.negative_sample)
+        neg = dpr.generate_negative_passage_ids(matcher, train_answers, q2id, p2id, I, train_pos_id, args.negative_sample,
+                                                pool=pool)
         os.makedirs(args.output_dir, exist_ok=True)
         train_path = os.path.join(args.output_dir, "ann_training_data_" + str(output_num))
         with open(train_path + ".tmp", "w") as f:
@@ -132,17 +133,18 @@ def generate_new_ann(args, output_num, checkpoint_path, preloaded_data, latest_s
     return result
 
 
-def ann_data_gen(args, engine=None, dist=None):
-    """Poll loop (run_ann_data_gen_dpr.py:519-553)."""
+def ann_data_gen(args, engine=None, dist=None, preloaded=None, pool=None):
+    """Poll loop (run_ann_data_gen_dpr.py:519-553).  ``preloaded`` / ``pool``: data and has_answer workers created
+    by ``main`` before the GPU was touched (otherwise loaded here, single-process matching)."""
     dist = dist or adg.Dist()
     last_checkpoint = args.last_checkpoint_dir
     ann_no, _, _ = adg.get_latest_ann_data(args.output_dir)
     output_num = ann_no + 1
-    preloaded = None
     if dist.rank == 0:
         os.makedirs(args.output_dir, exist_ok=True)
         os.makedirs(args.cache_dir, exist_ok=True)
-        preloaded = load_data(args)
+        if preloaded is None:
+            preloaded = load_data(args)
     while args.end_output_num == -1 or output_num <= args.end_output_num:
         next_checkpoint, latest_step_num = get_latest_checkpoint(args)
         if args.only_keep_latest_embedding_file:
@@ -151,7 +153,8 @@ def ann_data_gen(args, engine=None, dist=None):
             time.sleep(getattr(args, "poll_seconds", 60))
         else:
             logger.info("start generate ann data number %d", output_num)
-            generate_new_ann(args, output_num, next_checkpoint, preloaded, latest_step_num, engine=engine, dist=dist)
+            generate_new_ann(args, output_num, next_checkpoint, preloaded, latest_step_num, engine=engine, dist=dist,
+                             pool=pool)
             output_num += 1
             last_checkpoint = next_checkpoint
         dist.barrier()
@@ -182,15 +185,26 @@ def get_arguments(argv=None):
     p.add_argument("--trivia_test_qa_path", default=None, type=str, required=True)
     p.add_argument("--max_tokens", default=65536, type=int)
     p.add_argument("--seed", default=None, type=int)
+    p.add_argument("--host_workers", default=None, type=int, help="has_answer worker processes on rank 0 (default: up to 32)")
     return p.parse_args(argv)
 
 
 def main(argv=None):
     args = get_arguments(argv)
+    # Rank 0 loads the corpus text and fork()s the has_answer workers BEFORE the GPU / RCCL are initialised
+    # (the children share the 21 M-passage dict copy-on-write; forking after HIP initialisation is not safe).
+    preloaded = pool = None
+    if int(os.environ.get("RANK", "0")) == 0:
+        preloaded = load_data(args)
+        pool = dpr.AnswerPool(preloaded[0], getattr(args, "host_workers", None))
     adg.set_env(args)
     if args.seed is not None:
         random.seed(args.seed)
-    ann_data_gen(args)
+    try:
+        ann_data_gen(args, preloaded=preloaded, pool=pool)
+    finally:
+        if pool is not None:
+            pool.close()
 
 
 if __name__ == "__main__":

@@ -6,7 +6,9 @@ matching, top-k hit accuracy and answer-filtered negatives.
 answer as a contiguous token sub-sequence of the passage.  Passages are tokenised once and cached
 (the reference re-tokenises the same passage for every query that retrieves it).
 """
+import os
 import unicodedata
+from multiprocessing import get_context
 
 import numpy as np
 import regex
@@ -60,42 +62,93 @@ class AnswerMatcher:
         return False
 
 
-def validate(matcher, answers, closest_docs, query_embedding2id, passage_embedding2id):
+# ---- row-parallel workers ---------------------------------------------------------------------------
+# has_answer is the dominant host cost of the DPR job (about six million calls per refresh, each needing the
+# retrieved passage tokenised).  Rows are independent, so they are dealt to fork()ed workers that share the
+# 21 M-passage dict copy-on-write and keep their own token caches across refreshes.  The pool has to be
+# created BEFORE the process touches the GPU (fork after HIP initialisation is not safe): see
+# ann_data_gen_dpr.main.
+_WORKER_MATCHER = None
+
+
+def _hits_row(matcher, ans, doc_ids):
+    for rank, doc_id in enumerate(doc_ids):
+        if matcher.has_answer(ans, doc_id):
+            return rank
+    return -1
+
+
+def _negs_row(matcher, ans, doc_ids, pos_pid, negative_sample):
+    negs = []
+    examined = 0
+    for doc_id in doc_ids:
+        if doc_id == pos_pid or doc_id in negs:
+            continue
+        if examined >= negative_sample:
+            break
+        if not matcher.has_answer(ans, doc_id):
+            negs.append(doc_id)
+        examined += 1
+    return negs
+
+
+def _work(task):
+    kind, rows = task
+    m = _WORKER_MATCHER
+    if kind == "hits":
+        return [_hits_row(m, ans, docs) for ans, docs in rows]
+    return [_negs_row(m, ans, docs, pos, ns) for ans, docs, pos, ns in rows]
+
+
+class AnswerPool:
+    """fork()ed has_answer workers over ``passages`` ({pid_offset: (text, title)})."""
+
+    def __init__(self, passages, n_workers=None):
+        global _WORKER_MATCHER
+        n = n_workers if n_workers else min(32, os.cpu_count() or 1)
+        self.n_workers = max(1, int(n))
+        _WORKER_MATCHER = AnswerMatcher(passages)
+        self._pool = get_context("fork").Pool(self.n_workers) if self.n_workers > 1 else None
+
+    def map_rows(self, kind, rows):
+        if self._pool is None or len(rows) < 4 * self.n_workers:
+            return _work((kind, rows))
+        step = max(1, len(rows) // (self.n_workers * 8))
+        chunks = [(kind, rows[i:i + step]) for i in range(0, len(rows), step)]
+        out = []
+        for part in self._pool.imap(_work, chunks):
+            out.extend(part)
+        return out
+
+    def close(self):
+        if self._pool is not None:
+            self._pool.terminate()
+            self._pool = None
+
+
+def validate(matcher, answers, closest_docs, query_embedding2id, passage_embedding2id, pool=None):
     """Top-k hit accuracy list (run_ann_data_gen_dpr.py:312-340): entry i = fraction of questions whose
     first answer-bearing passage is at rank <= i."""
     p2id = np.asarray(passage_embedding2id)
     n_docs = closest_docs.shape[1]
+    rows = [(answers[int(query_embedding2id[row])], p2id[closest_docs[row]].tolist())
+            for row in range(closest_docs.shape[0])]
+    first = pool.map_rows("hits", rows) if pool is not None else [_hits_row(matcher, a, d) for a, d in rows]
     hits_at = np.zeros(n_docs, dtype=np.int64)
-    for row in range(closest_docs.shape[0]):
-        qid = int(query_embedding2id[row])
-        ans = answers[qid]
-        for rank, pidx in enumerate(closest_docs[row]):
-            if matcher.has_answer(ans, int(p2id[pidx])):
-                hits_at[rank:] += 1
-                break
+    for rank in first:
+        if rank >= 0:
+            hits_at[rank:] += 1
     return (hits_at / closest_docs.shape[0]).tolist()
 
 
 def generate_negative_passage_ids(matcher, answers, query_embedding2id, passage_embedding2id, closest_docs,
-                                  training_query_positive_id, negative_sample):
+                                  training_query_positive_id, negative_sample, pool=None):
     """Negatives = examined top candidates that lack every answer string (run_ann_data_gen_dpr.py:281-309).
     As in the reference, ``neg_cnt`` counts EXAMINED candidates (kept or not), so at most
     ``negative_sample`` of the first distinct non-positive candidates are looked at."""
     p2id = np.asarray(passage_embedding2id)
-    out = {}
-    for row in range(closest_docs.shape[0]):
-        qid = int(query_embedding2id[row])
-        pos_pid = training_query_positive_id[qid]
-        negs = []
-        examined = 0
-        for pidx in closest_docs[row]:
-            doc_id = int(p2id[pidx])
-            if doc_id == pos_pid or doc_id in negs:
-                continue
-            if examined >= negative_sample:
-                break
-            if not matcher.has_answer(answers[qid], doc_id):
-                negs.append(doc_id)
-            examined += 1
-        out[qid] = negs
-    return out
+    qids = [int(query_embedding2id[row]) for row in range(closest_docs.shape[0])]
+    rows = [(answers[qid], p2id[closest_docs[row]].tolist(), training_query_positive_id[qid], negative_sample)
+            for row, qid in enumerate(qids)]
+    res = pool.map_rows("negs", rows) if pool is not None else [_negs_row(matcher, *r) for r in rows]
+    return dict(zip(qids, res))

@@ -80,3 +80,28 @@ def test_load_data_formats(tmp_path):
     text, pos, ans, ta, tv = dprjob.load_data(a)
     assert pos == [1, 2] and ans == [["Paris", "paris france"], ["O'Neil"]] and ta == [["a", "b"]] and tv == [["c"]]
     assert text[0] == ('He said "hi" in Paris', "T0") and text[2] == ("third", "T2")
+
+
+def test_worker_pool_equals_serial(g):
+    """fork()ed has_answer workers (rows dealt in order) give exactly the serial results -- golden fixture
+    tiled to a few thousand rows, with duplicate candidate ids in a row."""
+    m = dpr.AnswerMatcher(g["passages"])
+    nq, n_p = g["I"].shape[0], len(g["passages"])
+    rng = np.random.default_rng(4)
+    reps = 60
+    I = np.concatenate([g["I"][rng.permutation(nq)] for _ in range(reps)], axis=0)
+    I[::11, 5] = I[::11, 2]  # a repeated candidate inside a row
+    answers = {q: g["answers"][q % nq] for q in range(I.shape[0])}
+    pos = {q: int(I[q, int(rng.integers(0, 6))]) for q in range(I.shape[0])}
+    q2id = np.arange(I.shape[0])
+    p2id = np.arange(n_p)
+    want_hits = dpr.validate(m, answers, I, q2id, p2id)
+    want_neg = dpr.generate_negative_passage_ids(m, answers, q2id, p2id, I, pos, g["negative_sample"])
+    pool = dpr.AnswerPool(g["passages"], n_workers=3)
+    try:
+        assert dpr.validate(m, answers, I, q2id, p2id, pool=pool) == want_hits
+        assert dpr.generate_negative_passage_ids(m, answers, q2id, p2id, I, pos, g["negative_sample"], pool=pool) == want_neg
+        # tiny inputs stay in-process
+        assert pool.map_rows("hits", [(answers[0], p2id[I[0]].tolist())]) == [dpr._hits_row(m, answers[0], p2id[I[0]].tolist())]
+    finally:
+        pool.close()
