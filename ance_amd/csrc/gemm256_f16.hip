@@ -168,7 +168,7 @@ __global__ void __launch_bounds__(G256_THREADS, 2) gemm256_f16_kernel(const Gemm
 
     if (!ABLATE || (G.debug_mode & (16 | 32))) {
         // product path: ping-pong pipeline of pipe256.h (debug_mode 16 + bits: its ablations)
-        Pipe256T<PipeSrcFixed, ABLATE, true> P;
+        Pipe256T<PipeSrcFixed, ABLATE, true, !ABLATE> P;  // product: coarse (2-phase) schedule; ablation build: the 4-phase one
         P.init(smem, w, l);
         P.dbg = G.debug_mode;
         P.S.dbg = ABLATE ? G.debug_mode : 0;

@@ -75,8 +75,18 @@ struct PipeSrcFixed {
 // DBG compiles measurement ablations in (dbg bit 1: no MFMA, bit 3: no staging); product code uses DBG = false.
 // KEEP_B0: hold the B-half0 fragments of a K-tile in 16 more VGPRs from phase c0 to c3 instead of reading
 // them from LDS a second time (the GEMM has the registers, the search filter does not).
-template <class SRC, bool DBG = false, bool KEEP_B0 = false>
+// COARSE (needs KEEP_B0): two phases per K-tile instead of four -- half as many barriers.
+//   phase P0: read A-half0, B-half0, B-half1   16 MFMA acc[0][0..1], acc[1][0..1]   + stage A-half1 of tile t+1
+//   phase P1: read A-half1                     16 MFMA acc[1][2..3], acc[0][2..3]   + stage A0, B0, B1 of tile t+2
+//   RAW  the wait at the end of the P1 reads of tile t-1 (vmcnt(2)) leaves only A-half1 of tile t in flight, so
+//        A0 / B0 / B1 of tile t are retired and the following barrier publishes them; the wait at the end of the
+//        P0 reads of tile t (vmcnt(6)) leaves only A0 / B0 / B1 of tile t+1 in flight, so A-half1 of tile t is
+//        retired before the barrier that precedes its read.
+//   WAR  as above: a half-tile last read in phase p is restaged in the MFMA half-phase of phase p+1 at the earliest
+//        (A0 / B0 / B1 read in P0 of tile t, restaged in P1 of tile t; A1 read in P1 of tile t, restaged in P0 of t+1).
+template <class SRC, bool DBG = false, bool KEEP_B0 = false, bool COARSE = false>
 struct Pipe256T {
+    static_assert(!COARSE || KEEP_B0, "the coarse schedule keeps both B halves in registers");
     SRC S;
     _Float16 *smem;
     int w, dbg = 0;
@@ -179,15 +189,79 @@ struct Pipe256T {
         mfma<0, 1, (MODE == 0 ? 1 : -1)>(acc, t + 2);
     }
 
+    // ---- coarse schedule ------------------------------------------------------------------------------
+    // MFMA half-phase of the coarse schedule: 16 MFMAs on A fragments fa (A-half YH) against both B halves, with
+    // N_STAGE LDS-DMA pieces (two per listed half-tile of K-tile ts) issued after every second MFMA.
+    template <int YH, int ST0, int ST1, int ST2>
+    __device__ __forceinline__ void mfma16(f32x16 (&acc)[2][4], int ts) {
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int step = 0; step < 8; ++step) {
+            // P0 runs B-half0 first (it was read first); P1 runs B-half1 first (either order is fine for the result:
+            // the two halves accumulate into different registers)
+            const int xx = (step >> 2) ^ YH, s = step & 3;
+#pragma unroll
+            for (int yy = 0; yy < 2; ++yy) {
+                const f16x8 &bf = xx == 0 ? fbk[s] : fb[s];
+                if (DBG && (dbg & 2)) {
+                    asm volatile("" ::"v"(bf), "v"(fa[yy][s]));
+                } else {
+                    acc[xx][2 * YH + yy] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf, fa[yy][s], acc[xx][2 * YH + yy], 0, 0, 0);
+                }
+            }
+            constexpr int n_stage = (ST0 >= 0) + (ST1 >= 0) + (ST2 >= 0);
+            if (step < 2 * n_stage) {  // one piece after each of the first 2 * n_stage MFMA pairs
+                __builtin_amdgcn_sched_barrier(0);
+                constexpr int types[3] = {ST0 >= 0 ? ST0 : 0, ST1 >= 0 ? ST1 : 0, ST2 >= 0 ? ST2 : 0};
+                if (step == 0) stage_piece<types[0], 0>(ts);
+                if (step == 1) stage_piece<types[0], 1>(ts);
+                if (step == 2) stage_piece<types[1], 0>(ts);
+                if (step == 3) stage_piece<types[1], 1>(ts);
+                if (step == 4) stage_piece<types[2], 0>(ts);
+                if (step == 5) stage_piece<types[2], 1>(ts);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    }
+
+    template <int MODE>
+    __device__ __forceinline__ void tile2(int t, f32x16 (&acc)[2][4]) {
+        // P0
+        read_a<0>(t);
+        read_b<0>(t);
+        read_b<1>(t);
+        if constexpr (MODE <= 1) PIPE_WAIT_VM(6); else PIPE_WAIT_VM(0);
+        if constexpr (MODE <= 1) mfma16<0, 1, -1, -1>(acc, t + 1); else mfma16<0, -1, -1, -1>(acc, t + 1);
+        // P1
+        read_a<1>(t);
+        if constexpr (MODE <= 1) PIPE_WAIT_VM(2);
+        if constexpr (MODE == 0) mfma16<1, 0, 2, 3>(acc, t + 2); else mfma16<1, -1, -1, -1>(acc, t + 2);
+    }
+
     // ---- building blocks of a K loop (all 512 threads) ----------------------------------------------
     // prologue: stage K-tile 0 and A0 B1 A1 of K-tile 1 (what the steady state has issued when a tile
     // starts), publish tile 0
     __device__ __forceinline__ void prologue() {
-        stage<0>(0); stage<2>(0); stage<3>(0); stage<1>(0); stage<0>(1); stage<3>(1); stage<1>(1);
-        PIPE_WAIT_VM(6);
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (COARSE) {
+            // tile 0 complete except its A-half1 (retired by the first P0 wait), then A0 B0 B1 of tile 1
+            stage<0>(0); stage<2>(0); stage<3>(0); stage<1>(0);
+            PIPE_WAIT_VM(2);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            stage<0>(1); stage<2>(1); stage<3>(1);
+        } else {
+            stage<0>(0); stage<2>(0); stage<3>(0); stage<1>(0); stage<0>(1); stage<3>(1); stage<1>(1);
+            PIPE_WAIT_VM(6);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
     // enter / leave the staggered section: wm = 1 runs one barrier behind wm = 0 in between
     __device__ __forceinline__ void enter() {
@@ -204,13 +278,21 @@ struct Pipe256T {
     // on return K-tiles NK and NK+1 are staged exactly as the prologue leaves tiles 0 and 1 (the wait
     // of the last c3 has retired tile NK).
     __device__ __forceinline__ void tiles_streaming(int NK, f32x16 (&acc)[2][4]) {
-        for (int t = 0; t < NK; ++t) tile<0>(t, acc);
+        for (int t = 0; t < NK; ++t) {
+            if constexpr (COARSE) tile2<0>(t, acc); else tile<0>(t, acc);
+        }
     }
     // K-tiles 0..NK-1 of a stream that ENDS: nothing beyond NK-1 is staged, no LDS-DMA left in flight.
     __device__ __forceinline__ void tiles_final(int NK, f32x16 (&acc)[2][4]) {
-        for (int t = 0; t < NK - 2; ++t) tile<0>(t, acc);
-        tile<1>(NK - 2, acc);
-        tile<2>(NK - 1, acc);
+        if constexpr (COARSE) {
+            for (int t = 0; t < NK - 2; ++t) tile2<0>(t, acc);
+            tile2<1>(NK - 2, acc);
+            tile2<2>(NK - 1, acc);
+        } else {
+            for (int t = 0; t < NK - 2; ++t) tile<0>(t, acc);
+            tile<1>(NK - 2, acc);
+            tile<2>(NK - 1, acc);
+        }
     }
 
     // Whole K loop of one output tile.  On return every wave has passed the same number of barriers.
