@@ -1,8 +1,6 @@
 """DPR refresh job end-to-end on an MI355X: two BERT towers from one DPR checkpoint file, four
 collections, answer-hit metrics and answer-filtered negatives; checked against the oracle (BERT [CLS]
 restatement, chain search) and for internal consistency.  Needs an MI355X."""
-import json
-import os
 import random
 import types
 

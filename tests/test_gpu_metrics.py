@@ -1,6 +1,5 @@
 """Offline-metrics searches on the MI355X (ance_amd.metrics): restricted-candidate scoring is bitwise the
 full scan's arithmetic, and the whole CLI runs from --inference dumps.  Needs an MI355X."""
-import os
 import pickle
 
 import numpy as np
