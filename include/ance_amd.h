@@ -72,10 +72,12 @@ size_t ance_ip_topk_workspace_bytes(int64_t n, int64_t nq, int d, int k);
  *   d_out_i   int64   [nq, k] global row ids; -1 where fewer than k rows exist
  * Requires n < 2^32, 1 <= k <= ANCE_TOPK_MAX_K.
  *
- * Two kernels produce the same bits: an fp32-MFMA scan (any shape), and -- when d % 64 == 0,
+ * Two kernels produce the same bits: an fp32-MFMA scan (any shape), and -- when d % 128 == 0,
  * k <= 256 and n >= 4096 -- a two-precision path: fp16 MFMA scores filter the corpus under a
- * rigorous error slack, every survivor is re-scored with the exact fp32 fmaf chain.  Both need
- * |x|, |q| < 65504 for the second.  ANCE_SEARCH=exact in the environment forces the first.
+ * rigorous error slack, every survivor is re-scored with the exact fp32 fmaf chain.  Row or
+ * query norms above 65504 (possible fp16 overflow) are detected on the device and the launch
+ * falls back to the scan by itself.  ANCE_SEARCH=exact in the environment forces the scan;
+ * ANCE_FAST_SPLITS=<power of two> overrides the corpus-split heuristic (tuning only).
  */
 int ance_ip_topk(const float *d_x, int64_t n, int64_t row_base, const float *d_q, int64_t nq, int d, int k,
                  float *d_out_d, int64_t *d_out_i, void *d_workspace, size_t workspace_bytes, void *stream);
