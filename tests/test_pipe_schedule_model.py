@@ -1,0 +1,148 @@
+"""Model check of the ping-pong main-loop schedules of ance_amd/csrc/pipe256.h (CPU only).
+
+The kernels keep LDS-DMA loads in flight across barriers with counted ``s_waitcnt vmcnt(N)`` and let two
+wave groups run one barrier apart, so correctness rests on a hazard argument (header of pipe256.h).
+This test restates the schedule tables -- what each phase reads, stages and waits for, in the prologue,
+the steady state and the two peeled tail tiles -- and replays them on a slot timeline for both wave
+groups, asserting for every K-tile count:
+
+  RAW  a half-tile is read only after BOTH groups retired their pieces of it with a wait that lies in
+       an earlier slot (a barrier separates slots), and it is the half-tile of the right K-tile;
+  WAR  a buffer is restaged only after both groups' reads of its previous occupant have completed
+       (a read completes in the MFMA half-phase that consumes it) in an earlier slot;
+  END  nothing is in flight when the loop ends, and every half-tile of every K-tile was read.
+
+vmcnt semantics: each wave's loads retire in issue order; ``wait(N)`` returns when at most N are
+outstanding.  A staged half-tile is two pieces per wave, so its count is 2.
+"""
+import pytest
+
+A0, A1, B0, B1 = 0, 1, 2, 3
+
+
+def four_phase(mode, t, keep_b0):
+    """Phases of K-tile t: (reads, wait or None, stages) -- pipe256.h ``tile<MODE>``."""
+    c3_reads = [] if keep_b0 else [(B0, t)]
+    return [
+        ([(A0, t), (B0, t)], None, [(B0, t + 1)] if mode <= 1 else []),
+        ([(B1, t)], None, [(A0, t + 2)] if mode == 0 else []),
+        ([(A1, t)], None, [(B1, t + 2)] if mode == 0 else []),
+        (c3_reads, {0: 4, 1: 0, 2: None}[mode], [(A1, t + 2)] if mode == 0 else []),
+    ]
+
+
+def four_phase_prologue():
+    # stage<0>(0) stage<2>(0) stage<3>(0) stage<1>(0) stage<0>(1) stage<3>(1) stage<1>(1); vmcnt(6); barrier
+    return [[(A0, 0), (B0, 0), (B1, 0), (A1, 0), (A0, 1), (B1, 1), (A1, 1)], 6, []]
+
+
+def coarse(mode, t):
+    """pipe256.h ``tile2<MODE>``."""
+    return [
+        ([(A0, t), (B0, t), (B1, t)], 6 if mode <= 1 else 0, [(A1, t + 1)] if mode <= 1 else []),
+        ([(A1, t)], 2 if mode <= 1 else None, [(A0, t + 2), (B0, t + 2), (B1, t + 2)] if mode == 0 else []),
+    ]
+
+
+def coarse_prologue():
+    # stage tile 0 (A0 B0 B1 A1); vmcnt(2); barrier; stage A0 B0 B1 of tile 1
+    return [[(A0, 0), (B0, 0), (B1, 0), (A1, 0)], 2, [(A0, 1), (B0, 1), (B1, 1)]]
+
+
+def replay(nk, phases_of, prologue):
+    """Replays a loop of ``nk`` K-tiles.  (The search filter's streamed loop over several corpus tiles is, from the
+    schedule's point of view, one longer loop: K-tile indices simply continue into the next corpus tile.)"""
+    total = nk
+    phases = []
+    for t in range(total):
+        mode = 0 if t < nk - 2 else (1 if t == nk - 2 else 2)
+        phases += phases_of(mode, t)
+    # per group: FIFO of outstanding (half_tile, tile), and the slot in which each half-tile was retired
+    fifo = {0: [], 1: []}
+    retired = {0: {}, 1: {}}       # (type, tile) -> slot of the wait that retired it
+    issued = {0: {}, 1: {}}        # (type, tile) -> slot of issue
+    read_done = {0: {}, 1: {}}     # (type, tile) -> slot in which the read was consumed
+
+    def wait_pieces(g, n_pieces, slot):
+        assert n_pieces % 2 == 0  # the fifo holds half-tiles, two pieces each
+        while len(fifo[g]) > n_pieces // 2:
+            retired[g][fifo[g].pop(0)] = slot
+
+    def stage(g, ht, slot):
+        typ, tile = ht
+        prev = (typ, tile - 2)
+        # WAR: both groups finished reading the previous occupant of this buffer in an earlier slot
+        if tile >= 2:
+            for gg in (0, 1):
+                assert prev in read_done[gg], "restage of %s before group %d read %s" % (ht, gg, prev)
+                assert read_done[gg][prev] < slot, "WAR: %s restaged in slot %d, group %d consumed %s in slot %d" % (
+                    ht, slot, gg, prev, read_done[gg][prev])
+        fifo[g].append(ht)
+        issued[g][ht] = slot
+
+    # prologue: both groups together in slot -1 (then the prologue barrier; then group 1's extra barrier)
+    pro_first, pro_wait, pro_second = prologue
+    for g in (0, 1):
+        for ht in pro_first:
+            stage(g, ht, -1)
+        wait_pieces(g, pro_wait, -1)
+        for ht in pro_second:
+            stage(g, ht, -1 if g == 0 else 0)  # issued after the prologue barrier, before the group's first phase
+    n_slots = 2 * len(phases) + 2
+    for slot in range(n_slots):
+        for g in (0, 1):
+            # group g: R(p) in slot 2p + g, M(p) in slot 2p + 1 + g
+            if (slot - g) % 2 == 0 and 0 <= (slot - g) // 2 < len(phases):
+                reads, w, _ = phases[(slot - g) // 2]
+                for ht in reads:
+                    # RAW: retired by both groups in an earlier slot
+                    for gg in (0, 1):
+                        assert ht in retired[gg], "read of %s in slot %d: group %d never waited for it" % (ht, slot, gg)
+                        assert retired[gg][ht] < slot, "RAW: %s read in slot %d, group %d retired it in slot %d" % (
+                            ht, slot, gg, retired[gg][ht])
+                if w is not None:
+                    wait_pieces(g, w, slot)
+            if (slot - g) % 2 == 1 and 0 <= (slot - g - 1) // 2 < len(phases):
+                p = (slot - g - 1) // 2
+                reads, _, stages = phases[p]
+                for ht in reads:
+                    read_done[g][ht] = slot  # consumed by this half-phase's MFMAs
+                for ht in stages:
+                    if ht[1] < total:
+                        stage(g, ht, slot)
+    for g in (0, 1):
+        assert not fifo[g], "loads left in flight: %s" % fifo[g]
+        for t in range(total):
+            for typ in (A0, A1, B0, B1):
+                assert (typ, t) in read_done[g], "half-tile %s of tile %d never read by group %d" % (typ, t, g)
+
+
+@pytest.mark.parametrize("nk", range(2, 14))
+@pytest.mark.parametrize("keep_b0", [False, True])
+def test_four_phase_schedule(nk, keep_b0):
+    replay(nk, lambda mode, t: four_phase(mode, t, keep_b0), four_phase_prologue())
+
+
+@pytest.mark.parametrize("nk", range(2, 14))
+def test_coarse_schedule(nk):
+    replay(nk, coarse, coarse_prologue())
+
+
+def test_model_catches_a_broken_schedule():
+    """The checker is not vacuous: restaging one phase earlier than allowed, or waiting for too little, fails."""
+    def early_restage(mode, t):
+        ph = four_phase(mode, t, False)
+        if mode == 0:  # stage A-half0 of tile t+2 already in phase c0 (its buffer is read in c0 of tile t)
+            ph[0] = (ph[0][0], ph[0][1], ph[0][2] + [(A0, t + 2)])
+            ph[1] = (ph[1][0], ph[1][1], [])
+        return ph
+    with pytest.raises(AssertionError):
+        replay(8, early_restage, four_phase_prologue())
+
+    def lazy_wait(mode, t):
+        ph = coarse(mode, t)
+        if mode == 0:
+            ph[1] = (ph[1][0], 4, ph[1][2])  # vmcnt(4) instead of vmcnt(2): B-half1 of the next tile may still be in flight
+        return ph
+    with pytest.raises(AssertionError):
+        replay(8, lazy_wait, coarse_prologue())
