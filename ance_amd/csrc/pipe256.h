@@ -35,6 +35,8 @@
 //        that wave's MFMAs of slot 2p+2 are issued (they consume it), and the barrier ending slot
 //        2p+2 comes before slot 2p+3.
 // Needs NK >= 2 K-tiles.  The last two tiles are peeled (nothing left to stage, smaller counts).
+// tests/test_pipe_schedule_model.py replays these tables (prologue, steady state, peeled tiles, both wave groups)
+// on a slot timeline and asserts the RAW / WAR conditions for every K-tile count.
 #pragma once
 #include "common.h"
 
