@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "libance_amd.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 ANCE_OK = 0
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 c_i32p = ctypes.POINTER(ctypes.c_int32)
 c_i64p = ctypes.POINTER(ctypes.c_int64)
@@ -39,6 +39,13 @@ SYMBOLS = {
     "ance_ip_topk": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64,
                                     ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                     ctypes.c_size_t, ctypes.c_void_p]),
+    "ance_ip_index_bytes": (ctypes.c_size_t, [ctypes.c_int64, ctypes.c_int]),
+    "ance_ip_index_build": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t,
+                                           ctypes.c_void_p]),
+    "ance_ip_topk_indexed_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int64, ctypes.c_int64, ctypes.c_int, ctypes.c_int]),
+    "ance_ip_topk_indexed": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
+                                            ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                            ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     "ance_topk_merge_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int64, ctypes.c_int]),
     "ance_topk_merge": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int,
                                        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t,

@@ -43,6 +43,7 @@ struct ScanParams {
     u64 *cand;         // [n_qt * S][TQ][C]
     u64 *part;         // [nq][S][k]
     const int *only_if;  // optional device flag: the whole launch is a no-op while it reads 0
+    const int *nq_dev;   // optional device count: only the first min(nq, *nq_dev) queries are searched
 };
 
 template <int NPL>
@@ -57,6 +58,10 @@ __global__ void __launch_bounds__(SCAN_THREADS, 2) ip_topk_scan_kernel(const Sca
     // group of GQ = 64/S query tiles x S splits: they stream the same corpus ranges at the same
     // time (X tiles shared through that XCD's L2) and keep only GQ query tiles hot.
     if (P.only_if && *P.only_if == 0) return;
+    uint32_t nq = P.nq;
+    if (P.nq_dev) nq = min(nq, (uint32_t)max(*P.nq_dev, 0));
+    if (nq == 0) return;
+    const int n_qt = (int)((nq + TQ - 1) / TQ);
     const int b = blockIdx.x;
     const int xcd = b & 7, jx = b >> 3;
     const int gq = 64 / P.S;
@@ -64,7 +69,7 @@ __global__ void __launch_bounds__(SCAN_THREADS, 2) ip_topk_scan_kernel(const Sca
     const int r64 = jx & 63;
     const int qt = grp * gq + r64 / P.S;
     const int split = r64 % P.S;
-    if (qt >= P.n_qt) return;
+    if (qt >= n_qt) return;
 
     const int tid = threadIdx.x;
     const int w = tid >> 6, l = tid & 63, g = l >> 5, c = l & 31;
@@ -92,8 +97,8 @@ __global__ void __launch_bounds__(SCAN_THREADS, 2) ip_topk_scan_kernel(const Sca
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const uint32_t qr = q0 + row_base_t + 32 * j;
-        if (qr < P.nq) qmask |= 1u << j;
-        qrow[j] = P.q + (size_t)min(qr, P.nq - 1) * d;
+        if (qr < nq) qmask |= 1u << j;
+        qrow[j] = P.q + (size_t)min(qr, nq - 1) * d;
     }
     const int lds_w_even = c4 * 2;        // float offset of {k0,k2} inside the row
     const int lds_w_odd = 16 + c4 * 2;    // float offset of {k1,k3}
@@ -173,7 +178,7 @@ __global__ void __launch_bounds__(SCAN_THREADS, 2) ip_topk_scan_kernel(const Sca
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb) {
             const int ql = wq * 64 + qb * 32 + c;
-            const bool qv = (q0 + ql) < P.nq;
+            const bool qv = (q0 + ql) < nq;
             const float tau = tau_s[ql];
             u64 *cq = cand + (size_t)ql * C;
 #pragma unroll
@@ -213,7 +218,7 @@ __global__ void __launch_bounds__(SCAN_THREADS, 2) ip_topk_scan_kernel(const Sca
     for (int i = 0; i < 32; ++i) {
         const int ql = w * 32 + i;
         const uint32_t qg = q0 + ql;
-        if (qg >= P.nq) continue;  // wave-uniform
+        if (qg >= nq) continue;  // wave-uniform
         const int n_c = __builtin_amdgcn_readfirstlane(cnt_s[ql]);
         const u64 *cq = cand + (size_t)ql * C;
         u64 *dst = P.part + ((size_t)qg * P.S + split) * (size_t)P.k;
@@ -257,8 +262,17 @@ bool make_plan(int64_t n, int64_t nq, int k, Plan *pl) {
 }  // namespace
 
 int launch_finalize_keys(const u64 *keys, int64_t nq, int m, int k, int64_t row_base, float *out_d, int64_t *out_i,
-                         hipStream_t st, const int *sel_flag, const u64 *alt_keys, int alt_m) {
-    const int P2 = next_pow2(m > alt_m ? m : alt_m);
+                         hipStream_t st, const FinalizeAlt *alt) {
+    FinalizeAlt a;
+    if (alt) a = *alt;
+    int widest = m + (a.dd ? DEDUP_MAXC * k : 0);
+    if (a.all_m > widest) widest = a.all_m;
+    if (a.slot_m > widest) widest = a.slot_m;
+    const int P2 = next_pow2(widest);
+    if (P2 > 8192) {
+        set_last_error("topk_finalize: more than 8192 survivors per query");
+        return ANCE_E_INVALID;
+    }
     static int attr_p2 = 0;
     if (P2 > attr_p2) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(topk_finalize_kernel<false>),
@@ -268,14 +282,30 @@ int launch_finalize_keys(const u64 *keys, int64_t nq, int m, int k, int64_t row_
     }
     ProfScope pf(PC_FINALIZE, st);
     hipLaunchKernelGGL(topk_finalize_kernel<false>, dim3((unsigned)nq), dim3(256), P2 * sizeof(u64), st, keys,
-                       (const float *)nullptr, (const int64_t *)nullptr, 1, nq, m, P2, k, row_base, out_d, out_i, sel_flag,
-                       alt_keys, alt_m);
+                       (const float *)nullptr, (const int64_t *)nullptr, 1, nq, m, P2, k, row_base, out_d, out_i, a);
+    return ANCE_OK;
+}
+
+int launch_reduce_keys(const u64 *keys, int nq_max, int m, int k, u64 *out, const int *nq_dev, hipStream_t st) {
+    const int P2 = next_pow2(m > k ? m : k);
+    if (P2 > 8192) {
+        set_last_error("topk_reduce_keys: more than 8192 keys per query");
+        return ANCE_E_INVALID;
+    }
+    static int attr_p2 = 0;
+    if (P2 > attr_p2) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(topk_reduce_keys_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)(P2 * sizeof(u64))) != hipSuccess)
+            return check_launch("topk_reduce_keys attr");
+        attr_p2 = P2;
+    }
+    hipLaunchKernelGGL(topk_reduce_keys_kernel, dim3((unsigned)nq_max), dim3(256), P2 * sizeof(u64), st, keys, m, P2, k, out, nq_dev);
     return ANCE_OK;
 }
 
 namespace {
 int launch_scan(const Plan &pl, const float *d_x, int64_t n, const float *q, int64_t nqc, int d, int k, u64 *cand, u64 *part,
-                const int *only_if, hipStream_t st) {
+                const int *only_if, const int *nq_dev, hipStream_t st) {
     auto scan = pl.npl == 8 ? ip_topk_scan_kernel<8> : (pl.npl == 16 ? ip_topk_scan_kernel<16> : ip_topk_scan_kernel<32>);
     static bool attr_done[3] = {false, false, false};
     const int ai = pl.npl == 8 ? 0 : (pl.npl == 16 ? 1 : 2);
@@ -288,11 +318,15 @@ int launch_scan(const Plan &pl, const float *d_x, int64_t n, const float *q, int
     ScanParams P;
     P.x = d_x; P.q = q; P.n = (uint32_t)n; P.nq = (uint32_t)nqc; P.d = d; P.k = k; P.S = pl.S;
     P.n_qt = (int)((nqc + TQ - 1) / TQ); P.n_tiles_p = pl.n_tiles_p; P.tiles_per_split = pl.tiles_per_split;
-    P.cand = cand; P.part = part; P.only_if = only_if;
+    P.cand = cand; P.part = part; P.only_if = only_if; P.nq_dev = nq_dev;
     const int gq = 64 / pl.S;
     const int groups = (P.n_qt + gq - 1) / gq;
     const unsigned blocks = (unsigned)((groups + 7) / 8 * 8) * 64u;
-    ProfScope ps(PC_SCAN, st, only_if ? 0.0 : 2.0 * (double)nqc * (double)n * (double)d);
+    if (only_if || nq_dev) {  // device-side conditional redo of the fast path: normally a no-op, kept out of the profile
+        hipLaunchKernelGGL(scan, dim3(blocks), dim3(SCAN_THREADS), SCAN_LDS_BYTES, st, P);
+        return ANCE_OK;
+    }
+    ProfScope ps(PC_SCAN, st, 2.0 * (double)nqc * (double)n * (double)d);
     hipLaunchKernelGGL(scan, dim3(blocks), dim3(SCAN_THREADS), SCAN_LDS_BYTES, st, P);
     return ANCE_OK;
 }
@@ -305,7 +339,7 @@ size_t exact_scan_fallback_bytes(int64_t n, int64_t nq, int k) {
 }
 
 int exact_scan_fallback(const float *d_x, int64_t n, const float *d_q, int64_t nq, int d, int k, void *d_ws, const int *only_if,
-                        const u64 **part_out, int *m_out, hipStream_t st) {
+                        const int *nq_dev, const u64 **part_out, int *m_out, hipStream_t st) {
     Plan pl;
     if (!make_plan(n, nq, k, &pl) || nq > pl.qc) {
         set_last_error("exact_scan_fallback: chunk too large");
@@ -315,7 +349,7 @@ int exact_scan_fallback(const float *d_x, int64_t n, const float *d_q, int64_t n
     u64 *cand = reinterpret_cast<u64 *>((char *)part + pl.part_bytes);
     *part_out = part;
     *m_out = pl.S * k;
-    return launch_scan(pl, d_x, n, d_q, nq, d, k, cand, part, only_if, st);
+    return launch_scan(pl, d_x, n, d_q, nq, d, k, cand, part, only_if, nq_dev, st);
 }
 
 }  // namespace ance
@@ -323,28 +357,30 @@ int exact_scan_fallback(const float *d_x, int64_t n, const float *d_q, int64_t n
 using namespace ance;
 
 namespace ance {
-size_t ip_topk_fast_workspace_bytes(int64_t n, int64_t nq, int d, int k);
-int ip_topk_fast(const float *d_x, int64_t n, int64_t row_base, const float *d_q, int64_t nq, int d, int k, float *d_out_d,
-                 int64_t *d_out_i, void *d_workspace, size_t workspace_bytes, hipStream_t st);
+size_t ip_index_bytes(int64_t n, int d);
+int ip_index_build(const float *d_x, int64_t n, int d, void *d_index, size_t index_bytes, hipStream_t st);
+size_t ip_topk_fast_workspace_bytes(int64_t n, int64_t nq, int d, int k, bool with_index);
+int ip_topk_fast(const float *d_x, int64_t n, int64_t row_base, const void *d_index, const float *d_q, int64_t nq, int d, int k,
+                 float *d_out_d, int64_t *d_out_i, void *d_workspace, size_t workspace_bytes, hipStream_t st);
 }
 
 // ANCE_SEARCH=exact forces the fp32-MFMA scan everywhere (A/B and cross-checks); default: the
-// two-precision path whenever the shape is eligible (d % 128 == 0, k <= 256, n >= 4096).
+// two-precision path whenever the shape is eligible (d % 128 == 0, d <= 2048, k <= 1024, n >= 4096).
 static bool fast_enabled() {
-    static int v = -1;
-    if (v < 0) {
-        const char *e = getenv("ANCE_SEARCH");
-        v = (e && !strcmp(e, "exact")) ? 0 : 1;
-    }
-    return v == 1;
+    const char *e = getenv("ANCE_SEARCH");
+    return !(e && !strcmp(e, "exact"));
+}
+
+static size_t scan_workspace_bytes(int64_t n, int64_t nq, int k) {
+    Plan pl;
+    if (!make_plan(n, nq, k, &pl)) return 0;
+    return pl.part_bytes + pl.cand_bytes + 256;
 }
 
 extern "C" size_t ance_ip_topk_workspace_bytes(int64_t n, int64_t nq, int d, int k) {
-    Plan pl;
-    if (!make_plan(n, nq, k, &pl)) return 0;
-    size_t need = pl.part_bytes + pl.cand_bytes + 256;
-    if (fast_enabled()) {
-        const size_t f = ip_topk_fast_workspace_bytes(n, nq, d, k);
+    size_t need = scan_workspace_bytes(n, nq, k);
+    if (need && fast_enabled()) {
+        const size_t f = ip_topk_fast_workspace_bytes(n, nq, d, k, true);
         if (f > need) need = f;
     }
     return need;
@@ -370,7 +406,7 @@ static int ip_topk_exact_scan(const float *d_x, int64_t n, int64_t row_base, con
     const int m = pl.S * k;
     for (int64_t q0 = 0; q0 < nq; q0 += pl.qc) {
         const int64_t nqc = (nq - q0) < pl.qc ? (nq - q0) : pl.qc;
-        int rc = launch_scan(pl, d_x, n, d_q + (size_t)q0 * d, nqc, d, k, cand, part, nullptr, st);
+        int rc = launch_scan(pl, d_x, n, d_q + (size_t)q0 * d, nqc, d, k, cand, part, nullptr, nullptr, st);
         if (rc) return rc;
         rc = launch_finalize_keys(part, nqc, m, k, row_base, d_out_d + (size_t)q0 * k, d_out_i + (size_t)q0 * k, st);
         if (rc) return rc;
@@ -378,11 +414,41 @@ static int ip_topk_exact_scan(const float *d_x, int64_t n, int64_t row_base, con
     return check_launch("ance_ip_topk");
 }
 
+static bool fast_args_ok(const float *d_x, const float *d_q, int64_t nq, float *d_out_d, int64_t *d_out_i, void *d_workspace) {
+    return nq > 0 && d_x && d_q && d_out_d && d_out_i && d_workspace && !((uintptr_t)d_x & 15) && !((uintptr_t)d_q & 15);
+}
+
 extern "C" int ance_ip_topk(const float *d_x, int64_t n, int64_t row_base, const float *d_q, int64_t nq, int d, int k,
                             float *d_out_d, int64_t *d_out_i, void *d_workspace, size_t workspace_bytes, void *stream) {
-    if (fast_enabled() && nq > 0 && d_x && d_q && d_out_d && d_out_i && d_workspace && !((uintptr_t)d_x & 15) &&
-        !((uintptr_t)d_q & 15) && ip_topk_fast_workspace_bytes(n, nq, d, k) > 0)
-        return ip_topk_fast(d_x, n, row_base, d_q, nq, d, k, d_out_d, d_out_i, d_workspace, workspace_bytes, (hipStream_t)stream);
+    if (fast_enabled() && fast_args_ok(d_x, d_q, nq, d_out_d, d_out_i, d_workspace) && ip_topk_fast_workspace_bytes(n, nq, d, k, true) > 0)
+        return ip_topk_fast(d_x, n, row_base, nullptr, d_q, nq, d, k, d_out_d, d_out_i, d_workspace, workspace_bytes,
+                            (hipStream_t)stream);
+    return ip_topk_exact_scan(d_x, n, row_base, d_q, nq, d, k, d_out_d, d_out_i, d_workspace, workspace_bytes, stream);
+}
+
+extern "C" size_t ance_ip_index_bytes(int64_t n, int d) { return fast_enabled() ? ip_index_bytes(n, d) : 0; }
+
+extern "C" int ance_ip_index_build(const float *d_x, int64_t n, int d, void *d_index, size_t index_bytes, void *stream) {
+    return ip_index_build(d_x, n, d, d_index, index_bytes, (hipStream_t)stream);
+}
+
+extern "C" size_t ance_ip_topk_indexed_workspace_bytes(int64_t n, int64_t nq, int d, int k) {
+    size_t need = scan_workspace_bytes(n, nq, k);
+    if (need && fast_enabled()) {
+        const size_t f = ip_topk_fast_workspace_bytes(n, nq, d, k, false);
+        if (f > need) need = f;
+    }
+    return need;
+}
+
+extern "C" int ance_ip_topk_indexed(const float *d_x, int64_t n, int64_t row_base, const void *d_index, const float *d_q, int64_t nq,
+                                    int d, int k, float *d_out_d, int64_t *d_out_i, void *d_workspace, size_t workspace_bytes,
+                                    void *stream) {
+    if (d_index && fast_enabled() && fast_args_ok(d_x, d_q, nq, d_out_d, d_out_i, d_workspace) &&
+        ip_topk_fast_workspace_bytes(n, nq, d, k, false) > 0)
+        return ip_topk_fast(d_x, n, row_base, d_index, d_q, nq, d, k, d_out_d, d_out_i, d_workspace, workspace_bytes,
+                            (hipStream_t)stream);
+    if (!d_index) return ance_ip_topk(d_x, n, row_base, d_q, nq, d, k, d_out_d, d_out_i, d_workspace, workspace_bytes, stream);
     return ip_topk_exact_scan(d_x, n, row_base, d_q, nq, d, k, d_out_d, d_out_i, d_workspace, workspace_bytes, stream);
 }
 
@@ -411,7 +477,7 @@ extern "C" int ance_topk_merge(const float *d_parts_d, const int64_t *d_parts_i,
     ProfScope pf(PC_FINALIZE, (hipStream_t)stream);
     hipLaunchKernelGGL(topk_finalize_kernel<true>, dim3((unsigned)nq), dim3(256), P2 * sizeof(u64), (hipStream_t)stream,
                        (const u64 *)nullptr, d_parts_d, d_parts_i, n_parts, nq, m, P2, k, (int64_t)0, d_out_d, d_out_i,
-                       (const int *)nullptr, (const u64 *)nullptr, 0);
+                       FinalizeAlt());
     return check_launch("ance_topk_merge");
 }
 

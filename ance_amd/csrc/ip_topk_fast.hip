@@ -3,21 +3,32 @@
 // gfx950 has no reduced-precision path for fp32 inputs (no xf32), and the exact fp32 MFMA runs at
 // 1/16 of the fp16 rate.  This kernel gets the fp16 rate WITHOUT giving up bit-exact results:
 //
-//   1. corpus and queries are rounded once to fp16 (xh = fp16(x));
+//   1. the corpus shard is turned ONCE into a search image (ance_ip_index_build): rows rounded to fp16
+//      (xh = fp16(x)), the maximum row norm, and -- when a sample of the shard shows heavy duplicate
+//      classes (the all-pad MaxP chunks of model/models.py:165-199 are millions of bit-identical rows)
+//      -- every class collapsed to its smallest row id; the image is compacted, `live2row` maps image
+//      rows back to shard rows and the first ids of every class are kept for the expansion in step 6;
 //   2. an approximate score  s~ = qh . xh  is a plain fp16 GEMM on the 256 x 256 x 64 direct-to-LDS
-//      main loop of gemm256_f16.hip (queries are the "m" side, so a lane owns a query);
+//      main loop of pipe256.h (queries are the "m" side, so a lane owns a query);
 //   3. with eps a rigorous bound on |s~ - s| (below) and t~ the k-th best APPROXIMATE score seen so
 //      far, a row with s~ < t~ - 2 eps can never be in the exact top-k (k rows have s >= t~ - eps
 //      > its s), so the per-query buffers keep exactly the rows with s~ >= t~ - 2 eps: about
-//      k + 2 eps * density rows (~270 for k = 200 on LayerNorm-distributed rows);
-//   4. when a block has scanned its corpus split, every kept row of every query is re-scored with
-//      the exact fp32 fmaf chain over k ascending (the contract of oracle/ip_topk_ref.c) -- one
-//      query per wave at a time, its fp32 row broadcast from LDS, 64 rows in flight -- and the exact
-//      top-k under (score desc, row asc) is selected from exact keys.  Output scores and ids are
-//      therefore bit-identical to the fp32-MFMA scan.
-//   If a buffer cannot be pruned below its capacity (more than ~1,500 rows inside one 2 eps band:
-//   pathologically clustered scores) the block raises a device-side flag and the launch chunk is
-//   redone by the exact scan kernel (conditional on the flag, no host synchronisation).
+//      k + 2 eps * density rows (~270 for k = 200 on LayerNorm-distributed rows).  The bound holds for
+//      t~ taken over ANY subset of rows, so the workgroups that scan different corpus splits for the same
+//      queries exchange their thresholds through global memory (stale values are merely weaker bounds);
+//   4. the corpus is scanned in WINDOWS of ~100 MB that every workgroup of the launch finishes before any
+//      moves on (a counter with a bounded spin: a scheduling hint, no data depends on it), so the 256 MB
+//      Infinity Cache serves all but the first reader of a corpus tile;
+//   5. when a block has scanned its share, the rows within 2 eps of the final k-th best approximate score
+//      are re-scored with the exact fp32 fmaf chain over k ascending (the contract of
+//      oracle/ip_topk_ref.c) -- one query per wave at a time, its fp32 row broadcast from LDS, 64 rows in
+//      flight -- and the exact top-k under (score desc, row asc) is selected from exact keys;
+//   6. topk_finalize merges the splits and, for every duplicate class whose representative survived, adds
+//      the class members (same exact score, ascending ids) before the final sort.
+//   A query whose buffer cannot be pruned below its capacity (more than ~1,800 rows inside one 2 eps
+//   band: pathologically clustered scores, fp16 overflow of that query) is appended to a device-side list
+//   and redone by the exact fp32 scan -- only those queries; above 1,024 such queries per launch chunk the
+//   whole chunk is redone.  Both are device-side conditionals, no host synchronisation.
 //
 // Error bound, B = sum_k |q_k||x_k| <= ||q|| ||x||, normal-range fp16 (|v| >= 2^-14):
 //   rounding q and x to fp16:  |q.x - qh.xh| <= (2^-11 + 2^-11 + 2^-22) B
@@ -27,6 +38,7 @@
 #include "common.h"
 #include "topk_common.h"
 #include "pipe256.h"
+#include <stdlib.h>
 
 namespace ance {
 namespace {
@@ -38,32 +50,284 @@ constexpr int F_THREADS = 512;
 constexpr int F_NPL = 32;
 constexpr int F_C = F_NPL * 64;  // 2048 buffered rows per (block, query); a tile can add 256
 constexpr size_t F_LDS_BYTES = (size_t)2 * F_STAGE_HALVES * sizeof(_Float16) + 3 * FQ * 4 + 16;
+constexpr int F_MAX_D = 2048;    // block-end re-scoring keeps 8 fp32 query rows + 8 position lists in the stage area
+constexpr int F_MAX_K = 1024;
+constexpr int OVF_CAP = 1024;    // overflowing queries per launch chunk that are redone one by one
 
-typedef __attribute__((address_space(3))) void lds_void_t;
-typedef const __attribute__((address_space(1))) void glb_void_t;
+// ---- search image of a shard (device memory, built by ance_ip_index_build) ----------------------------
+constexpr int IDX_BLOCK_ROWS = 1024;
+constexpr int IDX_SAMPLES = 2048;
+constexpr int IDX_MIN_CLASS = 8;  // a duplicate class is collapsed when >= 8 of the 2,048 sampled rows fall in it
 
-struct FastParams {
-    const _Float16 *q2;  // [nq, d]  fp16(q)
-    const _Float16 *x2;  // [n, d]   fp16(x)
-    const float *q32;    // [nq, d]
-    const float *x32;    // [n, d]
-    const float *qnorm;  // [nq]
-    const float *xmax;   // [1] max row norm of the shard
-    uint32_t n, nq;
-    int d, k, S, n_qt, n_tiles_p, tiles_per_split;
-    float slack_rel, slack_abs;
-    u64 *cand;  // [n_qt * S][FQ][F_C]
-    u64 *part;  // [nq][S][k]
-    int *overflow;  // [1] raised when a buffer cannot be pruned (the chunk is then redone exactly)
+struct IndexLayout {
+    size_t x2_off, live_off, mem_off, cls_off, blk_off, samp_off, total;
+    int64_t nb;
 };
+IndexLayout index_layout(int64_t n, int d) {
+    IndexLayout L;
+    L.nb = (n + IDX_BLOCK_ROWS - 1) / IDX_BLOCK_ROWS;
+    size_t o = 256;
+    L.x2_off = o; o += align_up((size_t)n * d * sizeof(_Float16), 256);
+    L.live_off = o; o += align_up((size_t)n * 4, 256);
+    L.mem_off = o; o += (size_t)DEDUP_MAXC * DEDUP_MEMCAP * 4;
+    L.cls_off = o; o += align_up((size_t)n + 4, 256);
+    L.blk_off = o; o += align_up((size_t)(1 + DEDUP_MAXC) * L.nb * 4, 256);
+    L.samp_off = o; o += (size_t)IDX_SAMPLES * sizeof(u64);
+    L.total = o;
+    return L;
+}
 
-// fp16 rounding + row norm (+ shard max): one wave per row, grid-stride, ONE atomic per block (a
-// single word saturates near 88 atomics/us: one per row would cost 100 ms on 8.8 M rows)
-__global__ void __launch_bounds__(256) round_rows_kernel(const float *src, int64_t rows, int d, _Float16 *dst, float *norm,
-                                                         unsigned int *maxnorm_bits) {
-    __shared__ float wmax[4];
+__device__ __forceinline__ u64 mix64(u64 z) {
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+// one wave per sampled row: position-mixed 64-bit hash of the row's bits; low 11 bits carry the sample index
+__global__ void __launch_bounds__(256) idx_sample_hash_kernel(const float *x, int64_t n, int d, u64 *samp) {
     const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int j = blockIdx.x * 4 + w;
+    if (j >= IDX_SAMPLES) return;
+    const int64_t row = (int64_t)(((unsigned __int128)(unsigned long long)j * (unsigned long long)n) / IDX_SAMPLES);
+    const uint32_t *s = reinterpret_cast<const uint32_t *>(x + (size_t)row * d);
+    u64 h = 0;
+    for (int k = l; k < d; k += 64) h += mix64(((u64)s[k] << 20) ^ (u64)(k + 1) * 0x9E3779B97F4A7C15ull);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) h += __shfl_xor(h, off);
+    if (l == 0) samp[j] = (h & ~2047ull) | (u64)j;
+}
+
+// one block: sort the sample keys, every run of >= IDX_MIN_CLASS equal hashes defines a duplicate class
+__global__ void __launch_bounds__(256) idx_find_classes_kernel(const u64 *samp, int64_t n, DedupHeader *H) {
+    __shared__ u64 s[IDX_SAMPLES];
+    __shared__ int ncls;
+    for (int i = threadIdx.x; i < IDX_SAMPLES; i += 256) s[i] = samp[i];
+    if (threadIdx.x == 0) ncls = 0;
+    __syncthreads();
+    bitonic_sort_desc(s, IDX_SAMPLES);
+    for (int i = threadIdx.x; i < IDX_SAMPLES; i += 256) {
+        if (i > 0 && (s[i] >> 11) == (s[i - 1] >> 11)) continue;  // not a run start
+        int len = 1;
+        while (i + len < IDX_SAMPLES && (s[i + len] >> 11) == (s[i] >> 11)) ++len;
+        if (len >= IDX_MIN_CLASS) {
+            const int c = atomicAdd(&ncls, 1);
+            if (c < DEDUP_MAXC) {
+                const int j = (int)(s[i] & 2047ull);
+                H->guess[c] = (uint32_t)(((unsigned __int128)(unsigned long long)j * (unsigned long long)n) / IDX_SAMPLES);
+                H->rep[c] = 0xFFFFFFFFu;
+                H->csize[c] = 0;
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        H->n_classes = ncls < DEDUP_MAXC ? ncls : DEDUP_MAXC;
+        H->n_live = (uint32_t)n;
+        H->xmax_bits = 0;
+    }
+}
+
+// class of every row (0xFF: none): a row belongs to class c when it is BIT-identical to the class's sample row.
+// A lane first compares the leading 16 bytes of its own row; only matches are compared in full by the wave.
+__global__ void __launch_bounds__(256) idx_classify_kernel(const float *x, int64_t n, int d, DedupHeader *H, uint8_t *cls) {
+    const int nc = H->n_classes;
+    if (nc == 0) return;
+    __shared__ uint32_t wmin[4][DEDUP_MAXC];
+    const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 head[DEDUP_MAXC];
+    uint32_t mn[DEDUP_MAXC];
+    for (int c = 0; c < DEDUP_MAXC; ++c) {
+        mn[c] = 0xFFFFFFFFu;
+        head[c] = *reinterpret_cast<const u32x4 *>(x + (size_t)H->guess[c < nc ? c : 0] * d);
+    }
+    const int64_t n_chunks = (n + 63) / 64;
+    for (int64_t ch = (int64_t)blockIdx.x * 4 + w; ch < n_chunks; ch += (int64_t)gridDim.x * 4) {
+        const int64_t row = ch * 64 + l;
+        const bool rv = row < n;
+        const u32x4 hv = *reinterpret_cast<const u32x4 *>(x + (size_t)(rv ? row : n - 1) * d);
+        uint8_t mine = 0xFF;
+        for (int c = 0; c < nc; ++c) {
+            u64 m = __ballot(rv && hv[0] == head[c][0] && hv[1] == head[c][1] && hv[2] == head[c][2] && hv[3] == head[c][3]);
+            const uint32_t *g = reinterpret_cast<const uint32_t *>(x + (size_t)H->guess[c] * d);
+            while (m) {
+                const int b = __builtin_ctzll(m);
+                m &= m - 1;
+                const uint32_t *r = reinterpret_cast<const uint32_t *>(x + (size_t)(ch * 64 + b) * d);
+                bool ne = false;
+                for (int k = l * 4; k < d; k += 256) {
+                    const u32x4 a = *reinterpret_cast<const u32x4 *>(r + k), bb = *reinterpret_cast<const u32x4 *>(g + k);
+                    ne |= a[0] != bb[0] || a[1] != bb[1] || a[2] != bb[2] || a[3] != bb[3];
+                }
+                if (__ballot(ne) == 0ull && l == b && mine == 0xFF) {
+                    mine = (uint8_t)c;
+                    mn[c] = min(mn[c], (uint32_t)row);
+                }
+            }
+        }
+        if (rv) cls[row] = mine;
+    }
+    for (int c = 0; c < nc; ++c) {
+        uint32_t v = mn[c];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v = min(v, (uint32_t)__shfl_xor((int)v, off));
+        if (l == 0) wmin[w][c] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < nc) {
+        const int c = threadIdx.x;
+        const uint32_t v = min(min(wmin[0][c], wmin[1][c]), min(wmin[2][c], wmin[3][c]));
+        if (v != 0xFFFFFFFFu) atomicMin(&H->rep[c], v);
+    }
+}
+
+
+// counter field of a row: 0 = stays in the image (no class, or the representative of its class), 1 + c = duplicate of class c
+__device__ __forceinline__ int idx_row_field(const DedupHeader *H, uint8_t c, uint32_t row) {
+    return (c == 0xFF || H->rep[c] == row) ? 0 : 1 + c;
+}
+
+// blk[f * nb + b] = rows of field f in block b (1,024 rows per block)
+__global__ void __launch_bounds__(256) idx_count_kernel(int64_t n, int64_t nb, const DedupHeader *H, const uint8_t *cls,
+                                                        uint32_t *blk) {
+    if (H->n_classes == 0) return;
+    __shared__ u64 ws[4];
+    const int64_t r0 = (int64_t)blockIdx.x * IDX_BLOCK_ROWS + threadIdx.x * 4;
+    u64 v = 0;  // five 12-bit fields (each <= 1024)
+    for (int j = 0; j < 4; ++j)
+        if (r0 + j < n) v += 1ull << (12 * idx_row_field(H, cls[r0 + j], (uint32_t)(r0 + j)));
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x <= DEDUP_MAXC) {
+        const u64 t = ws[0] + ws[1] + ws[2] + ws[3];
+        blk[(size_t)threadIdx.x * nb + blockIdx.x] = (uint32_t)((t >> (12 * threadIdx.x)) & 4095ull);
+    }
+}
+
+// one block: exclusive scan of every field over the blocks, in place; totals go to the header
+__global__ void __launch_bounds__(1024) idx_scan_kernel(int64_t nb, DedupHeader *H, uint32_t *blk) {
+    if (H->n_classes == 0) return;
+    __shared__ uint32_t sh[1024];
+    __shared__ uint32_t carry;
+    const int tid = threadIdx.x;
+    for (int f = 0; f <= DEDUP_MAXC; ++f) {
+        if (tid == 0) carry = 0;
+        __syncthreads();
+        for (int64_t b0 = 0; b0 < nb; b0 += 1024) {
+            const int64_t b = b0 + tid;
+            const uint32_t mine = b < nb ? blk[(size_t)f * nb + b] : 0u;
+            sh[tid] = mine;
+            __syncthreads();
+            for (int s = 1; s < 1024; s <<= 1) {
+                const uint32_t t = tid >= s ? sh[tid - s] : 0u;
+                __syncthreads();
+                sh[tid] += t;
+                __syncthreads();
+            }
+            if (b < nb) blk[(size_t)f * nb + b] = carry + sh[tid] - mine;
+            __syncthreads();
+            if (tid == 0) carry += sh[1023];
+            __syncthreads();
+        }
+        if (tid == 0) {
+            if (f == 0) H->n_live = carry;
+            else H->csize[f - 1] = carry;
+        }
+        __syncthreads();
+    }
+}
+
+// Builds the image: block b owns rows [1024 b, 1024 b + 1024).  Phase A ranks the block's rows inside their field
+// (image position of a kept row, ordinal of a duplicate inside its class); phase B rounds the kept rows to fp16 at
+// their image position (one wave per row) and folds their norms into the shard maximum.
+__global__ void __launch_bounds__(256) idx_compact_round_kernel(const float *x, int64_t n, int d, int64_t nb, DedupHeader *H,
+                                                                const uint8_t *cls, const uint32_t *blk, _Float16 *x2,
+                                                                uint32_t *live2row, uint32_t *members) {
+    __shared__ uint32_t pos_s[IDX_BLOCK_ROWS];  // image row of the block's rows, 0xFFFFFFFF for collapsed duplicates
+    __shared__ u64 wtot[4];
+    __shared__ float wmax[4];
+    const int tid = threadIdx.x, l = tid & 63, w = tid >> 6;
+    const int64_t r0 = (int64_t)blockIdx.x * IDX_BLOCK_ROWS;
+    const int nc = H->n_classes;
+    if (nc == 0) {
+        for (int j = tid; j < IDX_BLOCK_ROWS; j += 256) {
+            const int64_t row = r0 + j;
+            pos_s[j] = row < n ? (uint32_t)row : 0xFFFFFFFFu;
+            if (row < n) live2row[row] = (uint32_t)row;
+        }
+    } else {
+        int fld[4];
+        u64 v = 0;
+        for (int j = 0; j < 4; ++j) {
+            const int64_t row = r0 + tid * 4 + j;
+            fld[j] = row < n ? idx_row_field(H, cls[row], (uint32_t)row) : -1;
+            if (fld[j] >= 0) v += 1ull << (12 * fld[j]);
+        }
+        // exclusive prefix of the packed counters over the block's 256 threads (rows are in thread order)
+        u64 inc = v;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const u64 t = __shfl_up(inc, off);
+            if (l >= off) inc += t;
+        }
+        if (l == 63) wtot[w] = inc;
+        __syncthreads();
+        u64 base = 0;
+        for (int ww = 0; ww < w; ++ww) base += wtot[ww];
+        u64 run = base + inc - v;
+        for (int j = 0; j < 4; ++j) {
+            if (fld[j] < 0) continue;
+            const uint32_t row = (uint32_t)(r0 + tid * 4 + j);
+            const uint32_t rank = (uint32_t)((run >> (12 * fld[j])) & 4095ull);
+            const uint32_t at = blk[(size_t)fld[j] * nb + blockIdx.x] + rank;
+            if (fld[j] == 0) {
+                pos_s[tid * 4 + j] = at;
+                live2row[at] = row;
+            } else {
+                pos_s[tid * 4 + j] = 0xFFFFFFFFu;
+                if (at < (uint32_t)DEDUP_MEMCAP) members[(size_t)(fld[j] - 1) * DEDUP_MEMCAP + at] = row;
+            }
+            run += 1ull << (12 * fld[j]);
+        }
+    }
+    __syncthreads();
     float mymax = 0.0f;
+    for (int j = w; j < IDX_BLOCK_ROWS; j += 4) {
+        const uint32_t at = pos_s[j];
+        if (at == 0xFFFFFFFFu) continue;  // wave-uniform
+        const float *s = x + (size_t)(r0 + j) * d;
+        _Float16 *hi = x2 + (size_t)at * d;
+        float q = 0.f;
+        for (int k = l * 4; k < d; k += 256) {
+            const f32x4 vv = *reinterpret_cast<const f32x4 *>(s + k);
+            f16x4 h;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                h[e] = (_Float16)vv[e];
+                q = fmaf(vv[e], vv[e], q);
+            }
+            *reinterpret_cast<f16x4 *>(hi + k) = h;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) q += __shfl_xor(q, off);
+        float nr = sqrtf(q) * 1.0001f;  // the norm only feeds an upper bound
+        if (!(nr == nr)) nr = INFINITY;  // a NaN row must not hide from the fp16-trust test of the filter
+        mymax = fmaxf(mymax, nr);
+    }
+    // ONE atomic per block (a single word saturates near 88 atomics/us)
+    if (l == 0) wmax[w] = mymax;
+    __syncthreads();
+    if (tid == 0) {
+        const float m = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+        atomicMax(&H->xmax_bits, __builtin_bit_cast(unsigned int, m));
+    }
+}
+
+// fp16 rounding + row norm of the query chunk: one wave per row
+__global__ void __launch_bounds__(256) round_rows_kernel(const float *src, int64_t rows, int d, _Float16 *dst, float *norm) {
+    const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
     for (int64_t row = (int64_t)blockIdx.x * 4 + w; row < rows; row += (int64_t)gridDim.x * 4) {
         const float *s = src + (size_t)row * d;
         _Float16 *hi = dst + (size_t)row * d;
@@ -80,19 +344,39 @@ __global__ void __launch_bounds__(256) round_rows_kernel(const float *src, int64
         }
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) q += __shfl_xor(q, off);
-        const float nr = sqrtf(q) * 1.0001f;  // the norm only feeds an upper bound
-        if (l == 0 && norm) norm[row] = nr;
-        mymax = fmaxf(mymax, nr);
-    }
-    if (maxnorm_bits) {
-        if (l == 0) wmax[w] = mymax;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            const float m = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
-            atomicMax(maxnorm_bits, __builtin_bit_cast(unsigned int, m));
-        }
+        if (l == 0) norm[row] = sqrtf(q) * 1.0001f;  // NaN stays NaN: the filter's trust test is false for it
     }
 }
+
+// ---- per-launch control block (device, zeroed before every launch chunk) ------------------------------
+struct FastCtl {
+    unsigned int win_arrived;  // workgroups that finished a corpus window (monotonic over the launch)
+    int ovf_count;             // queries appended to ovf_list (may exceed OVF_CAP)
+    int fb_nq;                 // queries the per-query exact scan redoes (0 when the whole chunk is redone)
+    int fb_all;                // != 0: the whole chunk is redone by the exact scan
+};
+
+struct FastParams {
+    const _Float16 *q2;  // [nq, d]  fp16(q)
+    const _Float16 *x2;  // [n_live, d] fp16 image rows
+    const float *q32;    // [nq, d]
+    const float *x32;    // [n, d] shard rows
+    const float *qnorm;  // [nq]
+    const DedupHeader *hdr;
+    const uint32_t *live2row;
+    uint32_t nq;
+    int d, k, S, n_qt;
+    int Ws;              // corpus tiles per split per window (a window is S * Ws tiles)
+    int share;           // exchange thresholds between the splits of a query tile
+    unsigned int wait_ticks;  // bound of the window wait (100 MHz ticks)
+    float slack_rel, slack_abs;
+    u64 *cand;     // [n_qt * S][FQ][F_C]
+    u64 *part;     // [nq][S][k]
+    float *thr_g;  // [n_qt * S][FQ] published thresholds (NaN = none yet)
+    FastCtl *ctl;
+    int *ovf_flag;  // [nq] 0 / 1
+    int *ovf_list;  // [OVF_CAP]
+};
 
 // exact score: fp32 fmaf chain over k ascending from +0 (== v_mfma_f32_32x32x2_f32, == the oracle).
 // q comes from LDS (every lane of the wave works on the same query: broadcast reads), x from global
@@ -115,13 +399,13 @@ __device__ __forceinline__ float exact_ip_lds(const float *q_lds, const float *x
     return s;
 }
 
-// Source policy of the streamed main loop (pipe256.h): queries at fixed per-lane pointers, corpus rows
+// Source policy of the streamed main loop (pipe256.h): queries at fixed per-lane pointers, image rows
 // addressed from the tile origin p0 (clamped to the last row; rows past n are masked in the filter).
-// K-tile t >= NK belongs to the next corpus tile (p0 + 256).
+// K-tile t >= NK belongs to the NEXT corpus tile of this workgroup's sequence (origin p1).
 struct FastSrc {
     const _Float16 *q2, *x2;  // uniform bases
     uint32_t qoff[2][2];      // per-lane offsets (halves) of the query pieces: (clamped row) * d + chunk
-    uint32_t p0, n_last;
+    uint32_t p0, p1, n_last;
     int rs, ch, w, d, NK;     // rs = lane >> 3 (row inside a piece), ch = source chunk (same for both pieces)
     template <int TYPE, int J>
     __device__ __forceinline__ const _Float16 *addr(int t) const {
@@ -131,11 +415,15 @@ struct FastSrc {
             return q2 + (qoff[TYPE][J] + (uint32_t)(kk * 64));
         } else {
             const int r = (w + 8 * J) * 8 + rs;  // row of the half-tile
-            const uint32_t row = min(p0 + (nxt ? 256u : 0u) + (uint32_t)pipe_b_tile_row(TYPE - 2, r), n_last);
+            const uint32_t row = min((nxt ? p1 : p0) + (uint32_t)pipe_b_tile_row(TYPE - 2, r), n_last);
             return x2 + ((size_t)row * d + (uint32_t)(kk * 64 + ch));
         }
     }
 };
+
+__device__ __forceinline__ float load_thr(const float *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 __global__ void __launch_bounds__(F_THREADS, 2) ip_topk_fast_kernel(const FastParams P) {
     extern __shared__ __attribute__((aligned(16))) float smem_f[];
@@ -159,31 +447,37 @@ __global__ void __launch_bounds__(F_THREADS, 2) ip_topk_fast_kernel(const FastPa
     const int l = tid & 63, g = l >> 5, i = l & 31;
     const int wm = w >> 2, wn = w & 3;  // wave tile: 128 queries x 64 passages
     const uint32_t q0 = (uint32_t)qt * FQ;
-    const int t0 = split * P.tiles_per_split;
-    const int t1 = min(t0 + P.tiles_per_split, P.n_tiles_p);
     const int d = P.d;
+    const uint32_t n = P.hdr->n_live;  // rows of the image (device side: duplicates were collapsed there)
+    const int n_tiles = (int)((n + FP - 1) / FP);
+    const int W = P.Ws * P.S;
+    const int n_win = (n_tiles + W - 1) / W;
+    const unsigned n_part = (unsigned)(P.n_qt * P.S);
     u64 *cand = P.cand + ((size_t)qt * P.S + split) * (size_t)FQ * F_C;
+    float *thr_mine = P.thr_g + ((size_t)qt * P.S + split) * FQ;
+    const float *thr_tile = P.thr_g + (size_t)qt * P.S * FQ;
 
     if (tid < FQ) {
         const uint32_t qg = q0 + tid;
         thr_s[tid] = -INFINITY;
         cnt_s[tid] = 0;
-        const float qn = qg < P.nq ? P.qnorm[qg] : 0.0f, xm = P.xmax[0];
+        const float qn = qg < P.nq ? P.qnorm[qg] : 0.0f, xm = __builtin_bit_cast(float, P.hdr->xmax_bits);
         // the bound assumes no fp16 overflow: |x_j| <= ||x||, so norms <= 65504 exclude it.  Otherwise eps = inf
-        // keeps every row until the buffer overflows and the chunk is redone by the exact scan.
+        // keeps every row until the buffer overflows and the query is redone by the exact scan.
         const bool fp16_ok = qn <= 65504.0f && xm <= 65504.0f;  // false for NaN too
         eps2_s[tid] = fp16_ok ? 2.0f * (P.slack_rel * qn * xm + P.slack_abs * (qn + xm)) : INFINITY;
     }
 
-    // ---- main loop: the ping-pong pipeline of pipe256.h, streamed across this split's corpus tiles ----
-    // A operand = the block's 256 queries (re-read from L2 for every corpus tile), B operand = corpus
-    // rows.  K-tile index t of the tile being computed; t >= NK addresses the next corpus tile, so the
-    // LDS-DMA prefetch (5-6 phases ahead) runs through the filter step into the next tile.
+    // ---- main loop: the ping-pong pipeline of pipe256.h, streamed across this workgroup's corpus tiles ----
+    // A operand = the block's 256 queries (re-read from L2 for every corpus tile), B operand = image rows.
+    // Tile sequence: window by window, inside a window the Ws tiles of this split.  K-tile index t of the tile
+    // being computed; t >= NK addresses the next tile of the sequence, so the LDS-DMA prefetch (5-6 phases
+    // ahead) runs through the filter step into the next tile.
     Pipe256T<FastSrc> pipe;
     pipe.init(smem, w, l);
     {
         FastSrc &S = pipe.S;
-        S.q2 = P.q2; S.x2 = P.x2; S.d = d; S.n_last = P.n - 1; S.NK = d / FK; S.p0 = (uint32_t)t0 * FP;
+        S.q2 = P.q2; S.x2 = P.x2; S.d = d; S.n_last = n - 1; S.NK = d / FK;
         S.w = w; S.rs = l >> 3;
         S.ch = pipe_stage_chunk(pipe_stage_row(w, l, 0), l);  // rows of piece 1 are 64 further: same swizzle
 #pragma unroll
@@ -197,25 +491,44 @@ __global__ void __launch_bounds__(F_THREADS, 2) ip_topk_fast_kernel(const FastPa
     const int NK = d / FK;
     int *epoch_s = cnt_s + FQ;  // last tile (1-based) in which some wave asked for a prune
     if (tid == 0) *epoch_s = 0;
-    pipe.prologue();  // also publishes thr_s / cnt_s / eps2_s / epoch_s
 
-    for (int t = t0; t < t1; ++t) {
+    int t = split * P.Ws, jw = 0, win = 0;
+    bool have = t < n_tiles;
+    if (have) {
+        pipe.S.p0 = (uint32_t)t * FP;
+        pipe.S.p1 = pipe.S.p0;
+        pipe.prologue();  // also publishes thr_s / cnt_s / eps2_s / epoch_s
+    } else {
+        __syncthreads();
+    }
+
+    while (have) {
+        int tn, jn = jw + 1, winn = win;
+        if (jn < P.Ws) {
+            tn = t + 1;
+        } else {
+            jn = 0;
+            winn = win + 1;
+            tn = winn * W + split * P.Ws;
+        }
+        const bool have_n = tn < n_tiles;
         const uint32_t p0 = (uint32_t)t * FP;
         pipe.S.p0 = p0;
+        pipe.S.p1 = (uint32_t)tn * FP;
         f32x16 acc[2][4];
 #pragma unroll
         for (int x = 0; x < 2; ++x)
 #pragma unroll
             for (int y = 0; y < 4; ++y) acc[x][y] = f32x16{0};
         pipe.enter();
-        if (t + 1 < t1) pipe.tiles_streaming(NK, acc);
+        if (have_n) pipe.tiles_streaming(NK, acc);
         else pipe.tiles_final(NK, acc);
         pipe.leave();
 
         // ---- filter: keep every row whose approximate score is within 2 eps of the k-th best -------
         // acc[x][y][r]: passage = p0 + wn*64 + x*32 + (r&3) + 8 (r>>2) + 4 g ; query = q0 + wm*128 + y*32 + i
         const uint32_t pw0 = p0 + wn * 64 + 4 * g;
-        const bool ragged = p0 + FP > P.n;  // uniform: rows past n were staged as copies of row n-1
+        const bool ragged = p0 + FP > n;  // uniform: rows past n were staged as copies of row n-1
 #pragma unroll
         for (int y = 0; y < 4; ++y) {
             const int ql = wm * 128 + y * 32 + i;
@@ -240,7 +553,7 @@ __global__ void __launch_bounds__(F_THREADS, 2) ip_topk_fast_kernel(const FastPa
                 for (int r = 0; r < 16; ++r) {
                     const uint32_t prow = pw0 + x * 32 + (r & 3) + 8 * (r >> 2);
                     const float sc = acc[x][y][r];
-                    if (qv && prow < P.n && !(sc < thr)) {
+                    if (qv && prow < n && !(sc < thr)) {
                         const int sl = atomicAdd(&cnt_s[ql], 1);
                         cq[sl] = pack_key(sc, prow);
                     }
@@ -258,49 +571,84 @@ __global__ void __launch_bounds__(F_THREADS, 2) ip_topk_fast_kernel(const FastPa
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        if (*epoch_s != t + 1) continue;  // block-uniform
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        for (int qq = 0; qq < 32; ++qq) {
-            const int ql = w * 32 + qq;
-            const int n_c = __builtin_amdgcn_readfirstlane(cnt_s[ql]);
-            if (n_c > F_C - FP) {
-                u64 *cq = cand + (size_t)ql * F_C;
-                u64 keys[F_NPL];
+        if (*epoch_s == t + 1) {  // block-uniform
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            for (int qq = 0; qq < 32; ++qq) {
+                const int ql = w * 32 + qq;
+                const int n_c = __builtin_amdgcn_readfirstlane(cnt_s[ql]);
+                if (n_c > F_C - FP) {
+                    u64 *cq = cand + (size_t)ql * F_C;
+                    u64 keys[F_NPL];
 #pragma unroll
-                for (int j = 0; j < F_NPL; ++j) {
-                    const int idx = j * 64 + l;
-                    keys[j] = (idx < n_c) ? cq[idx] : 0ull;
-                }
-                u64 T = 0;  // k-th largest approximate key
-                for (int bit = 63; bit >= 0; --bit) {
-                    const u64 t2 = T | (1ull << bit);
-                    int ge = 0;
-#pragma unroll
-                    for (int j = 0; j < F_NPL; ++j) ge += __popcll(__ballot(keys[j] >= t2));
-                    if (ge >= P.k) T = t2;
-                }
-                const float thr_new = key_score(T) - eps2_s[ql];
-                int base = 0;
-                const u64 lt_mask = (1ull << l) - 1ull;
-#pragma unroll
-                for (int j = 0; j < F_NPL; ++j) {
-                    const bool keep = keys[j] != 0ull && !(key_score(keys[j]) < thr_new);
-                    const u64 m = __ballot(keep);
-                    if (keep) cq[base + __popcll(m & lt_mask)] = keys[j];
-                    base += __popcll(m);
-                }
-                if (l == 0) {
-                    if (base > F_C - FP) {  // more than 1,792 rows inside one 2 eps band: give up on this chunk
-                        atomicExch(P.overflow, 1);
-                        base = F_C - FP;
+                    for (int j = 0; j < F_NPL; ++j) {
+                        const int idx = j * 64 + l;
+                        keys[j] = (idx < n_c) ? cq[idx] : 0ull;
                     }
-                    cnt_s[ql] = base;
-                    thr_s[ql] = thr_new;
+                    u64 T = 0;  // k-th largest approximate key
+                    for (int bit = 63; bit >= 0; --bit) {
+                        const u64 t2 = T | (1ull << bit);
+                        int ge = 0;
+#pragma unroll
+                        for (int j = 0; j < F_NPL; ++j) ge += __popcll(__ballot(keys[j] >= t2));
+                        if (ge >= P.k) T = t2;
+                    }
+                    float thr_new = key_score(T) - eps2_s[ql];
+                    if (P.share) {  // what the other splits of this query have established is just as valid here
+                        float o = (l < P.S && l != split) ? load_thr(thr_tile + (size_t)l * FQ + ql) : -INFINITY;
+#pragma unroll
+                        for (int off = 16; off > 0; off >>= 1) o = fmaxf(o, __shfl_xor(o, off));  // S <= 32; NaN = none
+                        o = __shfl(o, 0);
+                        thr_new = fmaxf(thr_new, o);
+                    }
+                    int base = 0;
+                    const u64 lt_mask = (1ull << l) - 1ull;
+#pragma unroll
+                    for (int j = 0; j < F_NPL; ++j) {
+                        const bool keep = keys[j] != 0ull && !(key_score(keys[j]) < thr_new);
+                        const u64 m = __ballot(keep);
+                        if (keep) cq[base + __popcll(m & lt_mask)] = keys[j];
+                        base += __popcll(m);
+                    }
+                    if (l == 0) {
+                        if (base > F_C - FP) {  // more than 1,792 rows inside one 2 eps band: this query is redone exactly
+                            if (atomicExch(&P.ovf_flag[q0 + ql], 1) == 0) {
+                                const int slot = atomicAdd(&P.ctl->ovf_count, 1);
+                                if (slot < OVF_CAP) P.ovf_list[slot] = (int)(q0 + ql);
+                            }
+                            base = F_C - FP;
+                        }
+                        cnt_s[ql] = base;
+                        thr_s[ql] = thr_new;
+                        if (P.share) __hip_atomic_store(thr_mine + ql, thr_new, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
                 }
             }
         }
+        // ---- window boundary: wait (bounded) for the other workgroups, adopt their thresholds ----------
+        if (winn != win && winn < n_win) {  // block-uniform
+            if (tid == 0) {
+                __hip_atomic_fetch_add(&P.ctl->win_arrived, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (have_n && P.wait_ticks) {
+                    const unsigned target = (unsigned)(win + 1) * n_part;
+                    const unsigned long long t_in = wall_clock64();
+                    while (__hip_atomic_load(&P.ctl->win_arrived, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+                        __builtin_amdgcn_s_sleep(64);
+                        if (wall_clock64() - t_in > P.wait_ticks) break;
+                    }
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (P.share && tid < FQ) {
+                float m = thr_s[tid];
+                for (int s2 = 0; s2 < P.S; ++s2)
+                    if (s2 != split) m = fmaxf(m, load_thr(thr_tile + (size_t)s2 * FQ + tid));
+                thr_s[tid] = m;
+            }
+        }
         // thr_s / cnt_s updates are published by the barriers of the next tile's main loop
+        t = tn; jw = jn; win = winn; have = have_n;
     }
     __syncthreads();
 
@@ -310,8 +658,8 @@ __global__ void __launch_bounds__(F_THREADS, 2) ip_topk_fast_kernel(const FastPa
     // Re-scoring costs a 3 KB row read each, so the band is cut first: the k-th approximate key by the
     // same radix select, the survivors' buffer positions compacted into an LDS list (dense: every lane
     // re-scores one row per round), exact keys kept in registers and selected from there.
-    float *qrow_lds = smem_f + w * 1024;  // 4 KiB per wave in the idle stage area (d <= 1024)
-    unsigned short *list = reinterpret_cast<unsigned short *>(smem_f + 8 * 1024) + w * F_C;  // 4 KiB per wave
+    float *qrow_lds = smem_f + w * (d + F_C / 2);  // per wave in the idle stage area: d floats + 4 KiB of positions
+    unsigned short *list = reinterpret_cast<unsigned short *>(qrow_lds + d);
     const u64 lt_mask = (1ull << l) - 1ull;
     for (int qq = 0; qq < 32; ++qq) {
         const int ql = w * 32 + qq;
@@ -328,7 +676,7 @@ __global__ void __launch_bounds__(F_THREADS, 2) ip_topk_fast_kernel(const FastPa
             const int idx = j * 64 + l;
             keys[j] = (idx < n_c) ? cq[idx] : 0ull;
         }
-        float thr_band = -INFINITY;
+        float thr_band = thr_s[ql];  // rows buffered before the threshold rose (own prunes, other splits) are out as well
         if (n_c > P.k) {
             u64 T = 0;  // k-th largest approximate key
             for (int bit = 63; bit >= 0; --bit) {
@@ -338,7 +686,7 @@ __global__ void __launch_bounds__(F_THREADS, 2) ip_topk_fast_kernel(const FastPa
                 for (int j = 0; j < F_NPL; ++j) ge += __popcll(__ballot(keys[j] >= t2));
                 if (ge >= P.k) T = t2;
             }
-            thr_band = key_score(T) - eps2_s[ql];
+            thr_band = fmaxf(thr_band, key_score(T) - eps2_s[ql]);
         }
         int n_band = 0;
 #pragma unroll
@@ -357,7 +705,7 @@ __global__ void __launch_bounds__(F_THREADS, 2) ip_topk_fast_kernel(const FastPa
             const int e = r * 64 + l;
             u64 v = 0ull;
             if (e < n_band) {
-                const uint32_t prow = key_row(cq[list[e]]);
+                const uint32_t prow = P.live2row[key_row(cq[list[e]])];  // image row -> shard row
                 v = pack_key(exact_ip_lds(qrow_lds, P.x32 + (size_t)prow * d, d), prow);
             }
 #pragma unroll
@@ -377,65 +725,167 @@ __global__ void __launch_bounds__(F_THREADS, 2) ip_topk_fast_kernel(const FastPa
     }
 }
 
+// after the filter launch: turn the overflow list into the input of the per-query exact scan
+__global__ void __launch_bounds__(256) gather_overflow_kernel(FastCtl *ctl, const int *ovf_list, const float *q32, int d, float *qfb,
+                                                              int *fb_slot) {
+    const int cnt = ctl->ovf_count;
+    if (cnt == 0) return;
+    const int i = blockIdx.x;
+    if (cnt > OVF_CAP) {
+        if (i == 0 && threadIdx.x == 0) {
+            ctl->fb_all = 1;
+            ctl->fb_nq = 0;
+        }
+        return;
+    }
+    if (i == 0 && threadIdx.x == 0) ctl->fb_nq = cnt;
+    if (i >= cnt) return;
+    const int q = ovf_list[i];
+    for (int k = threadIdx.x * 4; k < d; k += 1024)
+        *reinterpret_cast<f32x4 *>(qfb + (size_t)i * d + k) = *reinterpret_cast<const f32x4 *>(q32 + (size_t)q * d + k);
+    if (threadIdx.x == 0) fb_slot[q] = i;
+}
+
 struct FastPlan {
-    int S, n_tiles_p, tiles_per_split;
+    int S, Ws;
     int64_t qc;  // queries per launch
-    size_t x2_bytes, q2_bytes, qn_bytes, cand_bytes, part_bytes, fallback_bytes;
+    size_t q2_bytes, qn_bytes, cand_bytes, part_bytes, thr_bytes, flag_bytes, qfb_bytes, fbk_bytes, fb_bytes, fball_bytes;
 };
 
+int env_int(const char *name, int dflt) {
+    const char *e = getenv(name);
+    return e && *e ? atoi(e) : dflt;
+}
+
+bool fast_shape_ok(int64_t n, int d, int k) {
+    return d >= 128 && d % 128 == 0 && d <= F_MAX_D && k >= 1 && k <= F_MAX_K && n >= 4096 && n < (1ll << 32);
+}
+
 bool make_fast_plan(int64_t n, int64_t nq, int d, int k, FastPlan *pl) {
-    if (d < 128 || d % 128 || k < 1 || k > 256 || n < 4096 || n >= (1ll << 32) || nq < 1) return false;
-    pl->n_tiles_p = (int)((n + FP - 1) / FP);
+    if (!fast_shape_ok(n, d, k) || nq < 1) return false;
+    const int n_tiles = (int)((n + FP - 1) / FP);
     const int64_t nqt = (nq + FQ - 1) / FQ;
-    const int64_t qct = nqt < 128 ? nqt : 128;
-    pl->qc = qct * FQ;
-    int S = 1;
-    while (qct * S < 256 && S < 32) S <<= 1;  // one workgroup per CU: more splits only add prologues and re-scoring
-    if (const char *e = getenv("ANCE_FAST_SPLITS")) {  // tuning knob (power of two, 1..32)
-        const int v = atoi(e);
-        if (v >= 1 && v <= 32 && (v & (v - 1)) == 0) S = v;
-    }
-    while (S > 1 && (S * 8 > pl->n_tiles_p || next_pow2(S * k) > 8192)) S >>= 1;
+    // One workgroup per CU: (query tiles per launch) x (corpus splits) = 256.  More splits = fewer query tiles per
+    // XCD (better L2 reuse of the query side) but one more candidate list per query; ANCE_FAST_SPLITS overrides.
+    int S = env_int("ANCE_FAST_SPLITS", 0);
+    if (S < 1 || S > 32 || (S & (S - 1))) S = 2;
+    while (nqt * S < 256 && S < 32) S <<= 1;
+    while (S > 1 && (S * 8 > n_tiles || next_pow2((S + DEDUP_MAXC) * k) > 8192)) S >>= 1;
     pl->S = S;
-    pl->tiles_per_split = (pl->n_tiles_p + S - 1) / S;
-    pl->x2_bytes = align_up((size_t)n * d * sizeof(_Float16), 256);
+    const int64_t qct = nqt < 256 / S ? nqt : 256 / S;
+    pl->qc = qct * FQ;
+    // window: ANCE_FAST_WINDOW_TILES corpus tiles of 256 rows (default 256 = 100 MB of fp16 rows at d = 768; 0 = one
+    // window, i.e. every split scans its contiguous share as the first version of this kernel did)
+    int Wt = env_int("ANCE_FAST_WINDOW_TILES", 256);
+    if (Wt <= 0 || Wt > n_tiles) Wt = n_tiles;
+    pl->Ws = (Wt + S - 1) / S;
     pl->q2_bytes = align_up((size_t)pl->qc * d * sizeof(_Float16), 256);
     pl->qn_bytes = align_up((size_t)pl->qc * sizeof(float), 256);
     pl->cand_bytes = (size_t)qct * S * FQ * F_C * sizeof(u64);
     pl->part_bytes = align_up((size_t)pl->qc * S * k * sizeof(u64), 256);
+    pl->thr_bytes = align_up((size_t)qct * S * FQ * sizeof(float) + (size_t)pl->qc * sizeof(int), 256);  // thr_g + fb_slot (0xFF fill)
+    pl->flag_bytes = align_up(256 + (size_t)pl->qc * sizeof(int) + OVF_CAP * sizeof(int), 256);           // ctl + ovf_flag + ovf_list (0 fill)
+    pl->qfb_bytes = align_up((size_t)OVF_CAP * d * sizeof(float), 256);
+    pl->fbk_bytes = align_up((size_t)OVF_CAP * k * sizeof(u64), 256);
     const int64_t nqc = nq < pl->qc ? nq : pl->qc;
-    pl->fallback_bytes = align_up(exact_scan_fallback_bytes(n, nqc, k), 256);
-    return pl->fallback_bytes > 0;
+    pl->fb_bytes = align_up(exact_scan_fallback_bytes(n, OVF_CAP, k), 256);
+    pl->fball_bytes = align_up(exact_scan_fallback_bytes(n, nqc, k), 256);
+    return pl->fb_bytes > 0 && pl->fball_bytes > 0;
+}
+
+size_t fast_search_bytes(const FastPlan &pl) {
+    return 256 + pl.q2_bytes + pl.qn_bytes + pl.part_bytes + pl.cand_bytes + pl.thr_bytes + pl.flag_bytes + pl.qfb_bytes +
+           pl.fbk_bytes + pl.fb_bytes + pl.fball_bytes;
 }
 
 }  // namespace
 
-size_t ip_topk_fast_workspace_bytes(int64_t n, int64_t nq, int d, int k) {
-    FastPlan pl;
-    if (!make_fast_plan(n, nq, d, k, &pl)) return 0;
-    return 256 + pl.x2_bytes + 256 + pl.q2_bytes + pl.qn_bytes + pl.cand_bytes + pl.part_bytes + pl.fallback_bytes;
+// ---- search image --------------------------------------------------------------------------------------
+size_t ip_index_bytes(int64_t n, int d) {
+    if (!fast_shape_ok(n, d, 1)) return 0;
+    return index_layout(n, d).total + 256;
 }
 
-int ip_topk_fast(const float *d_x, int64_t n, int64_t row_base, const float *d_q, int64_t nq, int d, int k, float *d_out_d,
-                 int64_t *d_out_i, void *d_workspace, size_t workspace_bytes, hipStream_t st) {
+int ip_index_build(const float *d_x, int64_t n, int d, void *d_index, size_t index_bytes, hipStream_t st) {
+    if (!fast_shape_ok(n, d, 1) || !d_x || !d_index || ((uintptr_t)d_x & 15)) {
+        set_last_error("ance_ip_index_build: shape not eligible (d % 128 == 0, 128 <= d <= 2048, 4096 <= n < 2^32)");
+        return ANCE_E_INVALID;
+    }
+    if (index_bytes < ip_index_bytes(n, d)) {
+        set_last_error("ance_ip_index_build: index buffer too small");
+        return ANCE_E_WORKSPACE;
+    }
+    const IndexLayout L = index_layout(n, d);
+    char *base = reinterpret_cast<char *>(align_up((uintptr_t)d_index, 256));
+    DedupHeader *H = reinterpret_cast<DedupHeader *>(base);
+    _Float16 *x2 = reinterpret_cast<_Float16 *>(base + L.x2_off);
+    uint32_t *live2row = reinterpret_cast<uint32_t *>(base + L.live_off);
+    uint32_t *members = reinterpret_cast<uint32_t *>(base + L.mem_off);
+    uint8_t *cls = reinterpret_cast<uint8_t *>(base + L.cls_off);
+    uint32_t *blk = reinterpret_cast<uint32_t *>(base + L.blk_off);
+    u64 *samp = reinterpret_cast<u64 *>(base + L.samp_off);
+    const bool dedup = env_int("ANCE_FAST_DEDUP", 1) != 0;
+    ProfScope ps(PC_PLAN, st);
+    (void)hipMemsetAsync(H, 0, 256, st);
+    if (dedup) {
+        hipLaunchKernelGGL(idx_sample_hash_kernel, dim3(IDX_SAMPLES / 4), dim3(256), 0, st, d_x, n, d, samp);
+        hipLaunchKernelGGL(idx_find_classes_kernel, dim3(1), dim3(256), 0, st, samp, n, H);
+        const unsigned cb = (unsigned)(((n + 63) / 64 + 3) / 4 < 4096 ? ((n + 63) / 64 + 3) / 4 : 4096);
+        hipLaunchKernelGGL(idx_classify_kernel, dim3(cb), dim3(256), 0, st, d_x, n, d, H, cls);
+        hipLaunchKernelGGL(idx_count_kernel, dim3((unsigned)L.nb), dim3(256), 0, st, n, L.nb, H, cls, blk);
+        hipLaunchKernelGGL(idx_scan_kernel, dim3(1), dim3(1024), 0, st, L.nb, H, blk);
+    }
+    hipLaunchKernelGGL(idx_compact_round_kernel, dim3((unsigned)L.nb), dim3(256), 0, st, d_x, n, d, L.nb, H, cls, blk, x2, live2row,
+                       members);
+    return check_launch("ance_ip_index_build");
+}
+
+size_t ip_topk_fast_workspace_bytes(int64_t n, int64_t nq, int d, int k, bool with_index) {
+    FastPlan pl;
+    if (!make_fast_plan(n, nq, d, k, &pl)) return 0;
+    return fast_search_bytes(pl) + (with_index ? ip_index_bytes(n, d) : 0);
+}
+
+// d_index: a search image built by ip_index_build for exactly (d_x, n, d), or NULL (then it is built inside the workspace)
+int ip_topk_fast(const float *d_x, int64_t n, int64_t row_base, const void *d_index, const float *d_q, int64_t nq, int d, int k,
+                 float *d_out_d, int64_t *d_out_i, void *d_workspace, size_t workspace_bytes, hipStream_t st) {
     FastPlan pl;
     if (!make_fast_plan(n, nq, d, k, &pl)) {
         set_last_error("ip_topk_fast: shape not eligible");
         return ANCE_E_INVALID;
     }
-    if (workspace_bytes < ip_topk_fast_workspace_bytes(n, nq, d, k)) {
+    if (workspace_bytes < ip_topk_fast_workspace_bytes(n, nq, d, k, d_index == nullptr)) {
         set_last_error("ip_topk_fast: workspace too small");
         return ANCE_E_WORKSPACE;
     }
     char *p = reinterpret_cast<char *>(align_up((uintptr_t)d_workspace, 256));
-    _Float16 *x2 = reinterpret_cast<_Float16 *>(p); p += pl.x2_bytes;
-    unsigned int *xmax = reinterpret_cast<unsigned int *>(p); p += 256;
     _Float16 *q2 = reinterpret_cast<_Float16 *>(p); p += pl.q2_bytes;
     float *qn = reinterpret_cast<float *>(p); p += pl.qn_bytes;
     u64 *part = reinterpret_cast<u64 *>(p); p += pl.part_bytes;
     u64 *cand = reinterpret_cast<u64 *>(p); p += pl.cand_bytes;
-    void *fb_ws = p;
-    int *overflow = reinterpret_cast<int *>(xmax) + 16;  // same 256-byte cell as the max norm
+    char *ff_area = p; p += pl.thr_bytes;    // 0xFF-filled per chunk
+    char *zero_area = p; p += pl.flag_bytes;  // zero-filled per chunk
+    float *qfb = reinterpret_cast<float *>(p); p += pl.qfb_bytes;
+    u64 *fb_keys = reinterpret_cast<u64 *>(p); p += pl.fbk_bytes;
+    void *fb_ws = p; p += pl.fb_bytes;
+    void *fball_ws = p; p += pl.fball_bytes;
+    if (!d_index) {
+        void *own = p;
+        const int rc = ip_index_build(d_x, n, d, own, ip_index_bytes(n, d), st);
+        if (rc) return rc;
+        d_index = own;
+    }
+    const IndexLayout L = index_layout(n, d);
+    const char *ibase = reinterpret_cast<const char *>(align_up((uintptr_t)d_index, 256));
+    const DedupHeader *H = reinterpret_cast<const DedupHeader *>(ibase);
+    const uint32_t *members = reinterpret_cast<const uint32_t *>(ibase + L.mem_off);
+
+    const int64_t qct = pl.qc / FQ;
+    float *thr_g = reinterpret_cast<float *>(ff_area);
+    int *fb_slot = reinterpret_cast<int *>(ff_area + (size_t)qct * pl.S * FQ * sizeof(float));
+    FastCtl *ctl = reinterpret_cast<FastCtl *>(zero_area);
+    int *ovf_flag = reinterpret_cast<int *>(zero_area + 256);
+    int *ovf_list = ovf_flag + pl.qc;
 
     static bool attr_done = false;
     if (!attr_done) {
@@ -444,28 +894,27 @@ int ip_topk_fast(const float *d_x, int64_t n, int64_t row_base, const float *d_q
             return check_launch("ip_topk_fast attr");
         attr_done = true;
     }
-    (void)hipMemsetAsync(xmax, 0, 128, st);
-    {
-        ProfScope ps(PC_PLAN, st);
-        hipLaunchKernelGGL(round_rows_kernel, dim3((unsigned)((n + 3) / 4 < 8192 ? (n + 3) / 4 : 8192)), dim3(256), 0, st, d_x, n, d, x2,
-                           (float *)nullptr, xmax);
-    }
     const float slack_rel = 1.25f * (9.765625e-4f + 2.1f * d * 5.9604645e-8f);
     const float slack_abs = 1.25f * 5.9604645e-8f * sqrtf((float)d);
+    const int share = env_int("ANCE_FAST_SHARE", 1);
+    const int wait_us = env_int("ANCE_FAST_WINDOW_WAIT_US", 200);
     for (int64_t q0 = 0; q0 < nq; q0 += pl.qc) {
         const int64_t nqc = (nq - q0) < pl.qc ? (nq - q0) : pl.qc;
+        (void)hipMemsetAsync(ff_area, 0xFF, pl.thr_bytes, st);
+        (void)hipMemsetAsync(zero_area, 0, pl.flag_bytes, st);
         {
             ProfScope ps(PC_PLAN, st);
             hipLaunchKernelGGL(round_rows_kernel, dim3((unsigned)((nqc + 3) / 4 < 8192 ? (nqc + 3) / 4 : 8192)), dim3(256), 0, st,
-                               d_q + (size_t)q0 * d, nqc, d, q2,
-                               qn, (unsigned int *)nullptr);
+                               d_q + (size_t)q0 * d, nqc, d, q2, qn);
         }
         FastParams P;
-        P.q2 = q2; P.x2 = x2; P.q32 = d_q + (size_t)q0 * d; P.x32 = d_x; P.qnorm = qn;
-        P.xmax = reinterpret_cast<const float *>(xmax);
-        P.n = (uint32_t)n; P.nq = (uint32_t)nqc; P.d = d; P.k = k; P.S = pl.S;
-        P.n_qt = (int)((nqc + FQ - 1) / FQ); P.n_tiles_p = pl.n_tiles_p; P.tiles_per_split = pl.tiles_per_split;
-        P.slack_rel = slack_rel; P.slack_abs = slack_abs; P.cand = cand; P.part = part; P.overflow = overflow;
+        P.q2 = q2; P.x2 = reinterpret_cast<const _Float16 *>(ibase + L.x2_off); P.q32 = d_q + (size_t)q0 * d; P.x32 = d_x; P.qnorm = qn;
+        P.hdr = H; P.live2row = reinterpret_cast<const uint32_t *>(ibase + L.live_off);
+        P.nq = (uint32_t)nqc; P.d = d; P.k = k; P.S = pl.S; P.Ws = pl.Ws;
+        P.n_qt = (int)((nqc + FQ - 1) / FQ);
+        P.share = share && pl.S > 1; P.wait_ticks = (unsigned)(wait_us > 0 ? wait_us * 100 : 0);
+        P.slack_rel = slack_rel; P.slack_abs = slack_abs; P.cand = cand; P.part = part; P.thr_g = thr_g; P.ctl = ctl;
+        P.ovf_flag = ovf_flag; P.ovf_list = ovf_list;
         const int gq = 32 / pl.S;
         const int groups = (P.n_qt + gq - 1) / gq;
         const unsigned blocks = (unsigned)((groups + 7) / 8 * 8) * 32u;
@@ -473,15 +922,22 @@ int ip_topk_fast(const float *d_x, int64_t n, int64_t row_base, const float *d_q
             ProfScope ps(PC_SCAN, st, 2.0 * (double)nqc * (double)n * (double)d);
             hipLaunchKernelGGL(ip_topk_fast_kernel, dim3(blocks), dim3(F_THREADS), F_LDS_BYTES, st, P);
         }
-        // pathological score clustering: the chunk is redone by the exact scan, device-side conditional
-        const u64 *fb_part = nullptr;
-        int fb_m = 0;
-        int rc = exact_scan_fallback(d_x, n, d_q + (size_t)q0 * d, nqc, d, k, fb_ws, overflow, &fb_part, &fb_m, st);
+        // queries whose buffers overflowed: redone by the exact scan, one by one (<= OVF_CAP) or as a whole chunk
+        hipLaunchKernelGGL(gather_overflow_kernel, dim3(OVF_CAP), dim3(256), 0, st, ctl, ovf_list, d_q + (size_t)q0 * d, d, qfb, fb_slot);
+        const u64 *fb_part = nullptr, *fball_part = nullptr;
+        int fb_m = 0, fball_m = 0;
+        int rc = exact_scan_fallback(d_x, n, qfb, OVF_CAP, d, k, fb_ws, nullptr, &ctl->fb_nq, &fb_part, &fb_m, st);
         if (rc) return rc;
-        rc = launch_finalize_keys(part, nqc, pl.S * k, k, row_base, d_out_d + (size_t)q0 * k, d_out_i + (size_t)q0 * k, st, overflow,
-                                  fb_part, fb_m);
+        rc = launch_reduce_keys(fb_part, OVF_CAP, fb_m, k, fb_keys, &ctl->fb_nq, st);
         if (rc) return rc;
-        if (q0 + pl.qc < nq) (void)hipMemsetAsync(overflow, 0, 4, st);
+        rc = exact_scan_fallback(d_x, n, d_q + (size_t)q0 * d, nqc, d, k, fball_ws, &ctl->fb_all, nullptr, &fball_part, &fball_m, st);
+        if (rc) return rc;
+        FinalizeAlt alt;
+        alt.sel_all = &ctl->fb_all; alt.all_keys = fball_part; alt.all_m = fball_m;
+        alt.slot = fb_slot; alt.slot_keys = fb_keys; alt.slot_m = k;
+        alt.dd = H; alt.members = members;
+        rc = launch_finalize_keys(part, nqc, pl.S * k, k, row_base, d_out_d + (size_t)q0 * k, d_out_i + (size_t)q0 * k, st, &alt);
+        if (rc) return rc;
     }
     return check_launch("ip_topk_fast");
 }

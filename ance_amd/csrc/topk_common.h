@@ -65,37 +65,93 @@ __device__ __forceinline__ void bitonic_sort_desc(u64 *s, int P2) {
     }
 }
 
+// ---- duplicate classes of a search image (ip_topk_fast.hip) ----------------------------------------------
+constexpr int DEDUP_MAXC = 4;       // classes of bit-identical rows collapsed per shard
+constexpr int DEDUP_MEMCAP = 1024;  // member ids kept per class (the smallest ones: no list needs more than k)
+struct DedupHeader {                // first 256 bytes of a search image
+    unsigned int xmax_bits;         // max row norm (float bits; +inf when a row norm is not finite)
+    unsigned int n_live;            // rows of the image (duplicates collapsed)
+    int n_classes;
+    int pad0;
+    unsigned int guess[DEDUP_MAXC]; // sampled row that defines the class
+    unsigned int rep[DEDUP_MAXC];   // smallest row id of the class: stays in the image
+    unsigned int csize[DEDUP_MAXC]; // members besides the representative
+};
+
+// where topk_finalize takes a query's survivors from when the fast path handed the query (or its whole launch
+// chunk) to the exact scan, and the duplicate classes to expand otherwise
+struct FinalizeAlt {
+    const int *sel_all = nullptr;   // != 0: every query of the chunk comes from all_keys [nq][all_m]
+    const u64 *all_keys = nullptr;
+    int all_m = 0;
+    const int *slot = nullptr;      // [nq] >= 0: this query comes from slot_keys [slot][slot_m]
+    const u64 *slot_keys = nullptr;
+    int slot_m = 0;
+    const DedupHeader *dd = nullptr;  // duplicate classes of the shard (survivors of the fast path only)
+    const uint32_t *members = nullptr;  // [DEDUP_MAXC][DEDUP_MEMCAP] ascending member ids
+};
+
 // FROM_DI = false: entries are packed keys [nq][m]; true: entries are (D, I) parts [n_parts][nq][k]
 template <bool FROM_DI>
 __global__ void __launch_bounds__(256) topk_finalize_kernel(const u64 *keys, const float *pd, const int64_t *pi,
                                                             int n_parts, int64_t nq, int m, int P2, int k,
                                                             int64_t row_base, float *out_d, int64_t *out_i,
-                                                            const int *sel_flag, const u64 *alt_keys, int alt_m) {
+                                                            const FinalizeAlt alt) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     u64 *s = reinterpret_cast<u64 *>(smem);
+    __shared__ unsigned int rep_hi[DEDUP_MAXC];  // ordered score bits of a class representative found among the survivors
     const int64_t qi = blockIdx.x;
-    if (!FROM_DI && sel_flag && *sel_flag) {  // the launch chunk was redone by the exact scan: take its survivors
-        keys = alt_keys;
-        m = alt_m;
+    bool expand = false;
+    if constexpr (!FROM_DI) {
+        keys += (size_t)qi * m;
+        expand = alt.dd && alt.dd->n_classes > 0;
+        if (alt.sel_all && *alt.sel_all) {  // the launch chunk was redone by the exact scan: take its survivors
+            keys = alt.all_keys + (size_t)qi * alt.all_m;
+            m = alt.all_m;
+            expand = false;  // the scan saw every row of the shard
+        } else if (alt.slot && alt.slot[qi] >= 0) {  // this query was redone by the exact scan
+            keys = alt.slot_keys + (size_t)alt.slot[qi] * alt.slot_m;
+            m = alt.slot_m;
+            expand = false;
+        }
     }
-    for (int i = threadIdx.x; i < P2; i += blockDim.x) {
+    const int nc = expand ? alt.dd->n_classes : 0;
+    const int m_all = m + nc * k;
+    int p2 = 1;
+    while (p2 < m_all) p2 <<= 1;  // <= P2 by construction of the launch
+    if (threadIdx.x < DEDUP_MAXC) rep_hi[threadIdx.x] = 0u;
+    __syncthreads();
+    for (int i = threadIdx.x; i < m; i += blockDim.x) {
         u64 v = 0ull;
-        if (i < m) {
-            if constexpr (FROM_DI) {
-                const int p = i / k, r = i - p * k;
-                const size_t o = ((size_t)p * nq + qi) * k + r;
-                const int64_t id = pi[o];
-                if (id >= 0) v = pack_key(pd[o], (uint32_t)id);
-            } else {
-                v = keys[(size_t)qi * m + i];
-            }
+        if constexpr (FROM_DI) {
+            const int p = i / k, r = i - p * k;
+            const size_t o = ((size_t)p * nq + qi) * k + r;
+            const int64_t id = pi[o];
+            if (id >= 0) v = pack_key(pd[o], (uint32_t)id);
+        } else {
+            v = keys[i];
+            if (v != 0ull)
+                for (int c = 0; c < nc; ++c)
+                    if (key_row(v) == alt.dd->rep[c]) rep_hi[c] = (unsigned int)(v >> 32);
         }
         s[i] = v;
     }
     __syncthreads();
-    bitonic_sort_desc(s, P2);
+    // a class whose representative survived: its members tie with it and follow it in ascending id order; the
+    // first k of them are all that can enter a top-k
+    for (int i = m + threadIdx.x; i < p2; i += blockDim.x) {
+        u64 v = 0ull;
+        if (i < m_all) {
+            const int c = (i - m) / k, r = (i - m) - c * k;
+            if (rep_hi[c] != 0u && (unsigned int)r < alt.dd->csize[c] && r < DEDUP_MEMCAP)
+                v = ((u64)rep_hi[c] << 32) | (u64)(0xFFFFFFFFu - alt.members[(size_t)c * DEDUP_MEMCAP + r]);
+        }
+        s[i] = v;
+    }
+    __syncthreads();
+    bitonic_sort_desc(s, p2);
     for (int i = threadIdx.x; i < k; i += blockDim.x) {
-        const u64 v = (i < P2) ? s[i] : 0ull;
+        const u64 v = (i < p2) ? s[i] : 0ull;
         const size_t o = (size_t)qi * k + i;
         if (v == 0ull) {
             out_d[o] = -FLT_MAX;
@@ -105,6 +161,18 @@ __global__ void __launch_bounds__(256) topk_finalize_kernel(const u64 *keys, con
             out_i[o] = row_base + (int64_t)key_row(v);
         }
     }
+    (void)P2;
+}
+
+// top-k keys of nq lists of m keys each (unsorted in, sorted out): the per-query exact-scan lists of the fast path
+static __global__ void __launch_bounds__(256) topk_reduce_keys_kernel(const u64 *keys, int m, int P2, int k, u64 *out, const int *nq_dev) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    u64 *s = reinterpret_cast<u64 *>(smem);
+    if (nq_dev && (int)blockIdx.x >= *nq_dev) return;
+    for (int i = threadIdx.x; i < P2; i += blockDim.x) s[i] = i < m ? keys[(size_t)blockIdx.x * m + i] : 0ull;
+    __syncthreads();
+    bitonic_sort_desc(s, P2);
+    for (int i = threadIdx.x; i < k; i += blockDim.x) out[(size_t)blockIdx.x * k + i] = i < P2 ? s[i] : 0ull;
 }
 
 
@@ -116,12 +184,14 @@ inline int next_pow2(int v) {
 
 // launches topk_finalize_kernel<false> over nq queries whose m = S*k survivors are packed keys
 int launch_finalize_keys(const u64 *keys, int64_t nq, int m, int k, int64_t row_base, float *out_d, int64_t *out_i,
-                         hipStream_t st, const int *sel_flag = nullptr, const u64 *alt_keys = nullptr, int alt_m = 0);
+                         hipStream_t st, const FinalizeAlt *alt = nullptr);
+int launch_reduce_keys(const u64 *keys, int nq_max, int m, int k, u64 *out, const int *nq_dev, hipStream_t st);
 
-// exact fp32-MFMA scan of one query chunk (nq <= 65,536), run only if *only_if != 0 (device side);
-// leaves m_out = S*k survivors per query at *part_out inside the given workspace.
+// exact fp32-MFMA scan of one query chunk (nq <= 65,536), device-side conditional: a no-op while *only_if == 0
+// (when given), over min(nq, *nq_dev) queries (when given); leaves m_out = S*k survivors per query at *part_out
+// inside the given workspace.
 size_t exact_scan_fallback_bytes(int64_t n, int64_t nq, int k);
 int exact_scan_fallback(const float *d_x, int64_t n, const float *d_q, int64_t nq, int d, int k, void *d_ws, const int *only_if,
-                        const u64 **part_out, int *m_out, hipStream_t st);
+                        const int *nq_dev, const u64 **part_out, int *m_out, hipStream_t st);
 
 }  // namespace ance

@@ -2,8 +2,12 @@
 (seam B5): ``idx = FlatIPIndex(d); idx.add(x); D, I = idx.search(q, k)``.
 
 Call sites it replaces: drivers/run_ann_data_gen.py:269-276,303 and
-drivers/run_ann_data_gen_dpr.py:238-252.  The corpus lives in HBM as fp32 [n, d]; search is the
-hand-written fp32-MFMA scan + fused top-k of csrc/ip_topk.hip through the C ABI ``ance_ip_topk``.
+drivers/run_ann_data_gen_dpr.py:238-252.  The corpus lives in HBM as fp32 [n, d].  ``add`` is lazy;
+the first search builds the shard's search image once (``ance_ip_index_build``: fp16 rows, duplicate
+classes) and every later search reuses it, like faiss reuses what ``add`` built.  Search itself is
+``ance_ip_topk_indexed``: the two-precision kernel of csrc/ip_topk_fast.hip (fp16 MFMA filter, exact
+fp32 re-scoring) where the shape allows it -- d % 128 == 0, d <= 2048, k <= ``FAST_MAX_K``, n >= 4096 --
+and the fp32-MFMA scan of csrc/ip_topk.hip otherwise (k up to ``MAX_K``); both return the same bits.
 Results follow the canonical order (score desc, row id asc), ``I = -1`` / ``D = -FLT_MAX`` when
 fewer than k rows exist (faiss' convention).  There is no CPU fallback.
 """
@@ -15,6 +19,9 @@ from . import _lib
 
 
 class FlatIPIndex:
+    MAX_K = 1792       # ANCE_TOPK_MAX_K
+    FAST_MAX_K = 1024  # above it (or d % 128 != 0, d > 2048, n < 4096) the fp32 scan answers: same bits, ~7x slower
+
     def __init__(self, d, device=None, row_base=0):
         import torch
         self.d = int(d)
@@ -24,6 +31,7 @@ class FlatIPIndex:
         self._parts = []
         self._x = None
         self._ws = None
+        self._image = None  # search image of self._x (device bytes), built on first use
 
     # -- faiss-like surface ---------------------------------------------------------------------
     @property
@@ -31,7 +39,7 @@ class FlatIPIndex:
         return sum(p.shape[0] for p in self._parts)
 
     def reset(self):
-        self._parts, self._x = [], None
+        self._parts, self._x, self._image = [], None, None
 
     def _to_device(self, a, what):
         import torch
@@ -54,6 +62,7 @@ class FlatIPIndex:
         how embeddings stay in the HBM of the GPU that encoded them."""
         self._parts.append(self._to_device(x, "x"))
         self._x = None
+        self._image = None
 
     def _matrix(self):
         import torch
@@ -78,26 +87,56 @@ class FlatIPIndex:
         return D, I
 
     # -- device-resident path -------------------------------------------------------------------
+    def _search_image(self, L, x):
+        """Device buffer holding the search image of ``x`` (None when the shape has none)."""
+        import torch
+        n = x.shape[0]
+        if self._image is None:
+            need = L.ance_ip_index_bytes(n, self.dp) if n else 0
+            if need == 0:
+                self._image = False
+            else:
+                buf = torch.empty(need, dtype=torch.uint8, device=self.device)
+                with torch.cuda.device(self.device):
+                    rc = L.ance_ip_index_build(ctypes.c_void_p(x.data_ptr()), n, self.dp, ctypes.c_void_p(buf.data_ptr()),
+                                               buf.numel(), _lib.current_stream_ptr())
+                _lib.check(rc, "ance_ip_index_build")
+                self._image = buf
+        return self._image if self._image is not False else None
+
     def search_device(self, qd, k):
         import torch
         L = _lib.lib()
         x = self._matrix()
         n, nq = x.shape[0], qd.shape[0]
+        if not 1 <= k <= self.MAX_K:
+            raise ValueError("k must be in [1, %d]" % self.MAX_K)
         D = torch.empty((nq, k), dtype=torch.float32, device=self.device)
         I = torch.empty((nq, k), dtype=torch.int64, device=self.device)
         if nq == 0:
             return D, I
-        need = L.ance_ip_topk_workspace_bytes(n, nq, self.dp, k)
+        img = self._search_image(L, x)
+        need = L.ance_ip_topk_indexed_workspace_bytes(n, nq, self.dp, k)
         if need == 0:
             raise _lib.AnceLibraryError("ance_ip_topk: unsupported (n=%d, nq=%d, k=%d)" % (n, nq, k))
         if self._ws is None or self._ws.numel() < need:
             self._ws = None
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
         with torch.cuda.device(self.device):
-            rc = L.ance_ip_topk(ctypes.c_void_p(x.data_ptr() if n else 0), n, self.row_base,
-                                ctypes.c_void_p(qd.data_ptr()), nq, self.dp, k,
-                                ctypes.c_void_p(D.data_ptr()), ctypes.c_void_p(I.data_ptr()),
-                                ctypes.c_void_p(self._ws.data_ptr()), self._ws.numel(), _lib.current_stream_ptr())
+            if img is not None:
+                rc = L.ance_ip_topk_indexed(ctypes.c_void_p(x.data_ptr()), n, self.row_base, ctypes.c_void_p(img.data_ptr()),
+                                            ctypes.c_void_p(qd.data_ptr()), nq, self.dp, k,
+                                            ctypes.c_void_p(D.data_ptr()), ctypes.c_void_p(I.data_ptr()),
+                                            ctypes.c_void_p(self._ws.data_ptr()), self._ws.numel(),
+                                            _lib.current_stream_ptr())
+            else:
+                need = L.ance_ip_topk_workspace_bytes(n, nq, self.dp, k)
+                if self._ws.numel() < need:
+                    self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+                rc = L.ance_ip_topk(ctypes.c_void_p(x.data_ptr() if n else 0), n, self.row_base,
+                                    ctypes.c_void_p(qd.data_ptr()), nq, self.dp, k,
+                                    ctypes.c_void_p(D.data_ptr()), ctypes.c_void_p(I.data_ptr()),
+                                    ctypes.c_void_p(self._ws.data_ptr()), self._ws.numel(), _lib.current_stream_ptr())
         _lib.check(rc, "ance_ip_topk")
         return D, I
 

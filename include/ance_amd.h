@@ -38,7 +38,7 @@ extern "C" {
 #define ANCE_E_LAUNCH (-3)    /* HIP reported a launch error */
 #define ANCE_E_NOMEM (-4)
 
-#define ANCE_ABI_VERSION 1
+#define ANCE_ABI_VERSION 2
 int ance_abi_version(void);
 /* last HIP error string seen by this library on the calling thread ("" if none) */
 const char *ance_last_error(void);
@@ -73,14 +73,40 @@ size_t ance_ip_topk_workspace_bytes(int64_t n, int64_t nq, int d, int k);
  * Requires n < 2^32, 1 <= k <= ANCE_TOPK_MAX_K.
  *
  * Two kernels produce the same bits: an fp32-MFMA scan (any shape), and -- when d % 128 == 0,
- * k <= 256 and n >= 4096 -- a two-precision path: fp16 MFMA scores filter the corpus under a
- * rigorous error slack, every survivor is re-scored with the exact fp32 fmaf chain.  Row or
- * query norms above 65504 (possible fp16 overflow) are detected on the device and the launch
- * falls back to the scan by itself.  ANCE_SEARCH=exact in the environment forces the scan;
- * ANCE_FAST_SPLITS=<power of two> overrides the corpus-split heuristic (tuning only).
+ * 128 <= d <= 2048, k <= 1024 and n >= 4096 -- a two-precision path: fp16 MFMA scores filter the
+ * corpus under a rigorous error slack, every survivor is re-scored with the exact fp32 fmaf chain.
+ * A query whose candidates cannot be bounded that way (row or query norms above 65504 or NaN, i.e.
+ * possible fp16 overflow; thousands of rows inside one error band) is detected on the device and
+ * redone by the scan, alone; heavy classes of bit-identical rows (all-pad MaxP chunks) are scored
+ * once and expanded in id order.  Environment (tuning / A-B only, read at every call):
+ *   ANCE_SEARCH=exact            force the scan
+ *   ANCE_FAST_SPLITS=<2^j>       corpus splits per query tile (default 2)
+ *   ANCE_FAST_WINDOW_TILES=<n>   corpus window all workgroups finish together, in 256-row tiles
+ *                                (default 256 = 100 MB of fp16 rows at d = 768; 0 = no windows)
+ *   ANCE_FAST_WINDOW_WAIT_US     bound of the wait at a window boundary (default 200, 0 = none)
+ *   ANCE_FAST_SHARE=0            do not exchange thresholds between the splits of a query
+ *   ANCE_FAST_DEDUP=0            do not collapse duplicate classes when an image is built
  */
 int ance_ip_topk(const float *d_x, int64_t n, int64_t row_base, const float *d_q, int64_t nq, int d, int k,
                  float *d_out_d, int64_t *d_out_i, void *d_workspace, size_t workspace_bytes, void *stream);
+
+/*
+ * Search image of a shard: what faiss.IndexFlatIP.add builds once and every .search reuses
+ * (drivers/run_ann_data_gen.py:269-276 adds once, :276 and :303 search twice).  ance_ip_topk rebuilds
+ * it inside its workspace on every call; a caller that searches the same rows repeatedly builds it once:
+ *   bytes = ance_ip_index_bytes(n, d)        0: the shape has no image (the scan is used), pass NULL
+ *   ance_ip_index_build(d_x, n, d, d_index, bytes, stream)
+ *   ance_ip_topk_indexed(d_x, n, row_base, d_index, ...)   with ance_ip_topk_indexed_workspace_bytes
+ * The image is valid for exactly the (d_x, n, d) it was built from; d_x must stay alive and unchanged
+ * (the exact re-scoring reads the fp32 rows).  Contents: fp16 rows (n d 2 bytes), row map, duplicate
+ * classes.  Results are those of ance_ip_topk, bit for bit.
+ */
+size_t ance_ip_index_bytes(int64_t n, int d);
+int ance_ip_index_build(const float *d_x, int64_t n, int d, void *d_index, size_t index_bytes, void *stream);
+size_t ance_ip_topk_indexed_workspace_bytes(int64_t n, int64_t nq, int d, int k);
+int ance_ip_topk_indexed(const float *d_x, int64_t n, int64_t row_base, const void *d_index, const float *d_q,
+                         int64_t nq, int d, int k, float *d_out_d, int64_t *d_out_i, void *d_workspace,
+                         size_t workspace_bytes, void *stream);
 
 /* Bytes of scratch ance_topk_merge needs. */
 size_t ance_topk_merge_workspace_bytes(int n_parts, int64_t nq, int k);

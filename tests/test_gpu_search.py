@@ -245,3 +245,222 @@ def test_sparse_candidates_after_threshold():
     x[39000:39050] = q[:50] * np.float32(1.5)   # late, far above every threshold, each matching one query
     x[20000:20010] = q[100:110] * np.float32(0.9)
     _check_exact("sparse_late", x, q, 50)
+
+
+# ---- round 2: windows, threshold exchange, search image reuse, duplicate classes, per-query redo ----------
+
+
+@pytest.mark.parametrize("splits,window", [("2", "8"), ("4", "16"), ("8", "8"), ("2", "0")])
+def test_windows_and_split_counts(monkeypatch, splits, window):
+    """60,000 rows = 235 corpus tiles scanned in windows of 8 / 16 tiles with 2, 4 and 8 splits per query tile
+    (thresholds exchanged between the splits at every window boundary and prune), and without windows."""
+    from oracle import synth
+    monkeypatch.setenv("ANCE_FAST_SPLITS", splits)
+    monkeypatch.setenv("ANCE_FAST_WINDOW_TILES", window)
+    rng = np.random.default_rng(31)
+    x = synth.ln_rows(rng, 60000)
+    x[59000:59040] = x[3]
+    q = np.concatenate([synth.ln_rows(rng, 299), x[3:4]])
+    _check_exact("win_%s_%s" % (splits, window), x, q, 200)
+
+
+def test_no_threshold_exchange_same_bits(monkeypatch):
+    from oracle import synth
+    rng = np.random.default_rng(32)
+    x = synth.ln_rows(rng, 30000)
+    q = synth.ln_rows(rng, 64)
+    D1, I1 = _search(x, q, 100)
+    monkeypatch.setenv("ANCE_FAST_SHARE", "0")
+    monkeypatch.setenv("ANCE_FAST_WINDOW_WAIT_US", "0")
+    D2, I2 = _search(x, q, 100)
+    assert np.array_equal(I1, I2) and np.array_equal(D1, D2)
+
+
+@pytest.mark.parametrize("d,k", [(2048, 50), (1152, 100), (4096, 20), (128, 200)])
+def test_wide_rows(d, k):
+    """d = 2048 is the widest row of the two-precision path (block-end re-scoring stages the fp32 query row in
+    LDS), d = 1152 is not a multiple of 128 and d = 4096 is too wide: both take the fp32 scan.  Same bits."""
+    rng = np.random.default_rng(d)
+    x = rng.standard_normal((6000, d)).astype(np.float32)
+    q = rng.standard_normal((70, d)).astype(np.float32)
+    _check_exact("wide_%d" % d, x, q, k)
+
+
+def test_k_1000_on_the_fast_path():
+    from oracle import synth
+    rng = np.random.default_rng(33)
+    x = synth.ln_rows(rng, 50000)
+    q = synth.ln_rows(rng, 48)
+    _check_exact("k1000", x, q, 1000)
+    _check_exact("k1024", x[:9000], q[:8], 1024)
+    _check_exact("k1025_scan", x[:9000], q[:8], 1025)
+
+
+def test_nan_row_is_not_trusted():
+    """A NaN in one corpus row poisons the norm bound of the whole shard: the launch must notice and every query
+    takes the exact scan, where (as in the oracle) a NaN score never enters a list."""
+    from oracle import synth
+    rng = np.random.default_rng(34)
+    x = synth.ln_rows(rng, 6000)
+    q = synth.ln_rows(rng, 20)
+    xb = x.copy()
+    xb[777, 3] = np.nan
+    D, I = _check_exact("nan_row", xb, q, 50)
+    assert not np.any(I == 777)
+
+
+def test_search_image_is_reused_and_invalidated():
+    import torch
+    from ance_amd.index import FlatIPIndex
+    from oracle import search_ref, synth
+    rng = np.random.default_rng(35)
+    x = synth.ln_rows(rng, 12000)
+    q = synth.ln_rows(rng, 33)
+    idx = FlatIPIndex(768)
+    idx.add(x[:8000])
+    D1, I1 = idx.search(q, 100)
+    img = idx._image
+    assert isinstance(img, torch.Tensor)
+    D2, I2 = idx.search(q[:5], 10)
+    assert idx._image is img  # second search: no rebuild
+    Do, Io = search_ref.flat_ip_topk_chain(x[:8000], q, 100)
+    assert np.array_equal(I1, Io) and np.array_equal(D1, Do)
+    assert np.array_equal(I2, Io[:5, :10])
+    idx.add(x[8000:])
+    assert idx._image is None
+    D3, I3 = idx.search(q, 100)
+    Do, Io = search_ref.flat_ip_topk_chain(x, q, 100)
+    assert np.array_equal(I3, Io) and np.array_equal(D3, Do)
+
+
+def _dup_corpus(rng, n, frac0, n1):
+    """LayerNorm rows with one heavy class of identical rows (fraction frac0 of the shard, scattered) and a second
+    class of n1 rows."""
+    from oracle import synth
+    x = synth.ln_rows(rng, n)
+    v0, v1 = synth.ln_rows(rng, 2)
+    m0 = rng.random(n) < frac0
+    m0[:5] = False       # the class does not start at row 0
+    x[m0] = v0
+    i1 = rng.choice(np.flatnonzero(~m0), size=n1, replace=False)
+    x[i1] = v1
+    return x, v0, v1, m0, i1
+
+
+def test_duplicate_classes_are_expanded_in_id_order():
+    """Half the shard is one vector v0 (the all-pad MaxP chunk of model/models.py:165-199), 3 % another: the image keeps one
+    row per class.  Queries: random ones, v0 itself (the whole top-k is the class, ascending ids), a mix where the class sits
+    mid-list, -v0 (class at the bottom: never returned)."""
+    from oracle import synth
+    rng = np.random.default_rng(36)
+    n = 40000
+    x, v0, v1, m0, i1 = _dup_corpus(rng, n, 0.5, 1200)
+    q = np.concatenate([synth.ln_rows(rng, 60), v0[None], v1[None], (0.6 * v0 + 0.8 * synth.ln_rows(rng, 1)[0])[None],
+                        -v0[None], (v0 + v1)[None]]).astype(np.float32)
+    for k in (10, 200, 1000):
+        D, I = _check_exact("dups_k%d" % k, x, q, k)
+    # v0 as the query: all k results are class members, ascending
+    assert np.all(m0[I[60]]) and np.all(np.diff(I[60]) > 0)
+
+
+def test_duplicate_classes_with_shards_and_row_base():
+    import torch
+    from ance_amd.index import topk_merge_device
+    from oracle import search_ref, synth
+    rng = np.random.default_rng(37)
+    n = 24000
+    x, v0, v1, m0, i1 = _dup_corpus(rng, n, 0.4, 600)
+    q = np.concatenate([synth.ln_rows(rng, 30), v0[None], (0.7 * v0 + 0.7 * v1)[None]]).astype(np.float32)
+    Do, Io = search_ref.flat_ip_topk_chain(x, q, 200)
+    per = n // 3
+    Dp, Ip = [], []
+    for s in range(3):
+        d_, i_ = _search(x[s * per:(s + 1) * per], q, 200, row_base=s * per)
+        Dp.append(d_)
+        Ip.append(i_)
+    Dm, Im = topk_merge_device(torch.from_numpy(np.stack(Dp)).cuda(), torch.from_numpy(np.stack(Ip)).cuda())
+    assert np.array_equal(Im.cpu().numpy(), Io) and np.array_equal(Dm.cpu().numpy(), Do)
+
+
+def test_dedup_off_same_bits(monkeypatch):
+    from oracle import synth
+    rng = np.random.default_rng(38)
+    x, v0, v1, m0, i1 = _dup_corpus(rng, 20000, 0.3, 300)
+    q = np.concatenate([synth.ln_rows(rng, 20), v0[None]]).astype(np.float32)
+    D1, I1 = _search(x, q, 100)
+    monkeypatch.setenv("ANCE_FAST_DEDUP", "0")   # the class then overflows the band of the v0 query: per-query redo
+    D2, I2 = _search(x, q, 100)
+    assert np.array_equal(I1, I2) and np.array_equal(D1, D2)
+
+
+def test_only_the_overflowing_queries_are_redone():
+    """3 of 400 queries see 6,000 rows inside one error band (rows = c + 1e-3 noise, too few to be sampled as a class);
+    the other 397 must come out of the fast path untouched and everything must match the oracle."""
+    from oracle import synth
+    rng = np.random.default_rng(39)
+    x = synth.ln_rows(rng, 50000)
+    c = synth.ln_rows(rng, 1)[0]
+    rows = rng.choice(50000, size=6000, replace=False)
+    x[rows] = (c[None, :] + 1e-3 * rng.standard_normal((6000, 768))).astype(np.float32)
+    q = synth.ln_rows(rng, 400)
+    q[[7, 200, 399]] = c * np.array([[1.0], [0.9], [1.1]], np.float32)
+    _check_exact("ovf_queries", x, q, 200)
+
+
+def test_more_overflowing_queries_than_the_redo_list():
+    """1,500 queries overflow (> 1,024): the whole launch chunk is redone by the scan."""
+    from oracle import search_ref, synth
+    rng = np.random.default_rng(40)
+    c = synth.ln_rows(rng, 1)[0]
+    x = (c[None, :] + 1e-3 * rng.standard_normal((8192, 768))).astype(np.float32)
+    q = (c[None, :] * (1.0 + 0.1 * rng.random((1500, 1)))).astype(np.float32)
+    D, I = _search(x, q, 100)
+    pick = rng.integers(0, 1500, 40)
+    Do, Io = search_ref.flat_ip_topk_chain(x, q[pick], 100)
+    assert np.array_equal(I[pick], Io) and np.array_equal(D[pick], Do)
+
+
+def test_dedup_at_scale_is_not_slower():
+    """2 M rows of which 1 M are one vector -- bit-exact on sampled queries against the oracle run on the
+    rows that can matter, and within 1.3x of the time of a corpus of distinct rows."""
+    import time
+    import torch
+    from ance_amd.index import FlatIPIndex
+    from oracle import search_ref
+    g = torch.Generator(device="cuda").manual_seed(41)
+    n, nq, k = 2_000_000, 4096, 200
+    x = torch.nn.functional.layer_norm(torch.randn((n, 768), generator=g, device="cuda"), (768,))
+    q = torch.nn.functional.layer_norm(torch.randn((nq, 768), generator=g, device="cuda"), (768,))
+
+    def timed(xx):
+        idx = FlatIPIndex(768)
+        idx.add(xx)
+        idx.search(q[:256], k)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        D, I = idx.search(q, k)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0, D.cpu().numpy(), I.cpu().numpy()
+
+    t_distinct, _, _ = timed(x)
+    v0 = x[123].clone()
+    dup = torch.rand((n,), generator=g, device="cuda") < 0.5
+    dup[:1000] = False
+    xd = torch.where(dup[:, None], v0[None, :], x)
+    q2 = q.clone()
+    q2[5] = v0           # whole list = the class
+    q2[6] = v0 + q[6]    # class somewhere in the list
+    q = q2
+    t_dup, D, I = timed(xd)
+    _diag("dedup_scale", t_distinct=t_distinct, t_dup=t_dup, n_dup=int(dup.sum().item()))
+    assert t_dup < 1.3 * t_distinct, (t_dup, t_distinct)
+    # oracle on: every non-class row that could matter is unknown, so check sampled queries against the chain
+    # scores of (their reported rows + a random sample + the first members of the class)
+    dup_ids = torch.nonzero(dup).flatten()[:400].cpu().numpy()
+    samp = torch.randint(0, n, (30000,), generator=torch.Generator().manual_seed(2)).numpy()
+    for r in (0, 5, 6, 1000, 4095):
+        rows = np.unique(np.concatenate([I[r], samp, dup_ids]))
+        xs = xd[torch.from_numpy(rows).cuda()].cpu().numpy()
+        Do, Io = search_ref.flat_ip_topk_chain(xs, q[r:r + 1].cpu().numpy(), k)
+        assert np.array_equal(rows[Io[0]], I[r]), r
+        assert np.array_equal(Do[0], D[r]), r
