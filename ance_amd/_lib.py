@@ -72,6 +72,7 @@ SYMBOLS = {
     "ance_host_write_ann_training": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
                                                     ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                                     ctypes.c_int, ctypes.POINTER(ctypes.c_int64)]),
+    "ance_debug_search_stamps": (None, [ctypes.c_void_p]),
     "ance_debug_gemm": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
                                        ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                        ctypes.c_void_p]),
@@ -133,7 +134,7 @@ def check(rc, what):
 
 
 PROFILE_CATEGORIES = ("plan", "embed_ln", "gemm_qk", "gemm_vt", "attention", "gemm_attn_out", "layernorm",
-                      "gemm_ffn1", "gemm_ffn2", "head", "ip_topk_scan", "topk_finalize")
+                      "gemm_ffn1", "gemm_ffn2", "head", "ip_topk_scan", "topk_finalize", "ip_topk_rescore")
 
 
 def profile_enable(on=True):

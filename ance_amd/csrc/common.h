@@ -20,7 +20,7 @@ int check_launch(const char *what);
 // ---- optional per-kernel timing with HIP events on the launch stream (bench.py's roofline) ----
 enum ProfCat {
     PC_PLAN = 0, PC_EMBED, PC_GEMM_QK, PC_GEMM_VT, PC_ATTN, PC_GEMM_OUT, PC_LN, PC_GEMM_FFN1, PC_GEMM_FFN2, PC_HEAD,
-    PC_SCAN, PC_FINALIZE, PC_COUNT
+    PC_SCAN, PC_FINALIZE, PC_RESCORE, PC_COUNT
 };
 bool prof_enabled();
 void prof_begin(int cat, hipStream_t st, double work);

@@ -362,7 +362,10 @@ int ip_index_build(const float *d_x, int64_t n, int d, void *d_index, size_t ind
 size_t ip_topk_fast_workspace_bytes(int64_t n, int64_t nq, int d, int k, bool with_index);
 int ip_topk_fast(const float *d_x, int64_t n, int64_t row_base, const void *d_index, const float *d_q, int64_t nq, int d, int k,
                  float *d_out_d, int64_t *d_out_i, void *d_workspace, size_t workspace_bytes, hipStream_t st);
+void set_fast_stamps(unsigned long long *d_stamps);
 }
+
+extern "C" void ance_debug_search_stamps(void *d_stamps) { ance::set_fast_stamps(reinterpret_cast<unsigned long long *>(d_stamps)); }
 
 // ANCE_SEARCH=exact forces the fp32-MFMA scan everywhere (A/B and cross-checks); default: the
 // two-precision path whenever the shape is eligible (d % 128 == 0, d <= 2048, k <= 1024, n >= 4096).

@@ -49,7 +49,7 @@ constexpr int F_STAGE_HALVES = 2 * F_OPER_HALVES;
 constexpr int F_THREADS = 512;
 constexpr int F_NPL = 32;
 constexpr int F_C = F_NPL * 64;  // 2048 buffered rows per (block, query); a tile can add 256
-constexpr size_t F_LDS_BYTES = (size_t)2 * F_STAGE_HALVES * sizeof(_Float16) + 3 * FQ * 4 + 16;
+constexpr size_t F_LDS_BYTES = (size_t)2 * F_STAGE_HALVES * sizeof(_Float16) + 4 * FQ * 4 + 16;
 constexpr int F_MAX_D = 2048;    // block-end re-scoring keeps 8 fp32 query rows + 8 position lists in the stage area
 constexpr int F_MAX_K = 1024;
 constexpr int OVF_CAP = 1024;    // overflowing queries per launch chunk that are redone one by one
@@ -252,6 +252,7 @@ __global__ void __launch_bounds__(256) idx_compact_round_kernel(const float *x, 
     const int64_t r0 = (int64_t)blockIdx.x * IDX_BLOCK_ROWS;
     const int nc = H->n_classes;
     if (nc == 0) {
+        if (blockIdx.x == 0 && tid == 0) H->n_live = (uint32_t)n;  // (not set by anyone when the class search is off)
         for (int j = tid; j < IDX_BLOCK_ROWS; j += 256) {
             const int64_t row = r0 + j;
             pos_s[j] = row < n ? (uint32_t)row : 0xFFFFFFFFu;
@@ -278,7 +279,10 @@ __global__ void __launch_bounds__(256) idx_compact_round_kernel(const float *x, 
         for (int ww = 0; ww < w; ++ww) base += wtot[ww];
         u64 run = base + inc - v;
         for (int j = 0; j < 4; ++j) {
-            if (fld[j] < 0) continue;
+            if (fld[j] < 0) {  // past the end of the shard
+                pos_s[tid * 4 + j] = 0xFFFFFFFFu;
+                continue;
+            }
             const uint32_t row = (uint32_t)(r0 + tid * 4 + j);
             const uint32_t rank = (uint32_t)((run >> (12 * fld[j])) & 4095ull);
             const uint32_t at = blk[(size_t)fld[j] * nb + blockIdx.x] + rank;
@@ -373,58 +377,99 @@ struct FastParams {
     u64 *cand;     // [n_qt * S][FQ][F_C]
     u64 *part;     // [nq][S][k]
     float *thr_g;  // [n_qt * S][FQ] published thresholds (NaN = none yet)
+    int *cnt_g;    // [n_qt * S][FQ] rows left in every buffer (for rescore_kernel)
     FastCtl *ctl;
     int *ovf_flag;  // [nq] 0 / 1
     int *ovf_list;  // [OVF_CAP]
+    unsigned int *grp_ctr;  // [groups] tiles finished by the workgroups of an XCD group (tile_sync)
+    int prune_at;           // first prune of a list at this many rows (<= F_C - FP); later ones when the list has doubled
+    int tile_sync;          // keep the 32 workgroups of an XCD group on the same corpus tile step (bounded wait)
+    unsigned int tile_wait_ticks;
+    unsigned long long *stamps;  // measurement: [workgroup][8] accumulated 100 MHz ticks (STAMPS kernel only)
 };
 
 // exact score: fp32 fmaf chain over k ascending from +0 (== v_mfma_f32_32x32x2_f32, == the oracle).
 // q comes from LDS (every lane of the wave works on the same query: broadcast reads), x from global
 // memory with 16 independent 16-byte loads in flight per lane.
 __device__ __forceinline__ float exact_ip_lds(const float *q_lds, const float *x, int d) {
+    // d % 128 == 0.  Two 64-float batches in flight: the loads of the next batch are issued before the 64 dependent
+    // fmas of the current one, so only the first batch's memory latency is exposed.
     float s = 0.0f;
-    for (int k0 = 0; k0 < d; k0 += 64) {
-        f32x4 xv[16];
+    f32x4 xa[16], xb[16];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) xv[j] = *reinterpret_cast<const f32x4 *>(x + k0 + 4 * j);
+    for (int j = 0; j < 16; ++j) xa[j] = *reinterpret_cast<const f32x4 *>(x + 4 * j);
+    for (int k0 = 0; k0 < d; k0 += 128) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) xb[j] = *reinterpret_cast<const f32x4 *>(x + k0 + 64 + 4 * j);
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             const f32x4 a = *reinterpret_cast<const f32x4 *>(q_lds + k0 + 4 * j);
-            s = __builtin_fmaf(a[0], xv[j][0], s);
-            s = __builtin_fmaf(a[1], xv[j][1], s);
-            s = __builtin_fmaf(a[2], xv[j][2], s);
-            s = __builtin_fmaf(a[3], xv[j][3], s);
+            s = __builtin_fmaf(a[0], xa[j][0], s);
+            s = __builtin_fmaf(a[1], xa[j][1], s);
+            s = __builtin_fmaf(a[2], xa[j][2], s);
+            s = __builtin_fmaf(a[3], xa[j][3], s);
+        }
+        const int kn = k0 + 128 < d ? k0 + 128 : 0;  // (the last iteration re-reads the row's head: result unused)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) xa[j] = *reinterpret_cast<const f32x4 *>(x + kn + 4 * j);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const f32x4 a = *reinterpret_cast<const f32x4 *>(q_lds + k0 + 64 + 4 * j);
+            s = __builtin_fmaf(a[0], xb[j][0], s);
+            s = __builtin_fmaf(a[1], xb[j][1], s);
+            s = __builtin_fmaf(a[2], xb[j][2], s);
+            s = __builtin_fmaf(a[3], xb[j][3], s);
         }
     }
     return s;
 }
 
-// Source policy of the streamed main loop (pipe256.h): queries at fixed per-lane pointers, image rows
-// addressed from the tile origin p0 (clamped to the last row; rows past n are masked in the filter).
-// K-tile t >= NK belongs to the NEXT corpus tile of this workgroup's sequence (origin p1).
+// Source policy of the streamed main loop (pipe256.h).  Both operands go through buffer descriptors (wave-uniform
+// SGPRs) + one 32-bit per-lane byte offset per staged piece that never changes during the kernel, + the K offset in an
+// SGPR: 8 address VGPRs in all.  (With flat 64-bit addresses hipcc keeps a pointer pair per piece for the current AND
+// the next corpus tile, spills, and every spill reload in the tile loop is a vmcnt(0) that drains the prefetch.)
+// The descriptor of a corpus tile covers exactly its rows that exist (<= 256), the one of the query tile its real
+// queries: rows past the end read as zeros (hardware range check) and are masked in the filter.
+// K-tile t >= NK belongs to the NEXT corpus tile of this workgroup's sequence (descriptor rx1).
 struct FastSrc {
-    const _Float16 *q2, *x2;  // uniform bases
-    uint32_t qoff[2][2];      // per-lane offsets (halves) of the query pieces: (clamped row) * d + chunk
-    uint32_t p0, p1, n_last;
-    int rs, ch, w, d, NK;     // rs = lane >> 3 (row inside a piece), ch = source chunk (same for both pieces)
+    __amdgpu_buffer_rsrc_t rq, rx0, rx1;
+    uint32_t voff[4][2];  // [A-half0, A-half1, B-half0, B-half1][piece]: (row of the 256-row tile) * d * 2 + chunk * 2 bytes
+    int NK;
     template <int TYPE, int J>
-    __device__ __forceinline__ const _Float16 *addr(int t) const {
+    __device__ __forceinline__ void issue(int t, pipe_lds_t *dst) const {
         const bool nxt = t >= NK;
-        const int kk = nxt ? t - NK : t;
-        if constexpr (TYPE < 2) {
-            return q2 + (qoff[TYPE][J] + (uint32_t)(kk * 64));
-        } else {
-            const int r = (w + 8 * J) * 8 + rs;  // row of the half-tile
-            const uint32_t row = min((nxt ? p1 : p0) + (uint32_t)pipe_b_tile_row(TYPE - 2, r), n_last);
-            return x2 + ((size_t)row * d + (uint32_t)(kk * 64 + ch));
-        }
+        const int so = (nxt ? t - NK : t) * (FK * 2);
+        if constexpr (TYPE < 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rq, dst, 16, voff[TYPE][J], so, 0, 0);
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(nxt ? rx1 : rx0, dst, 16, voff[TYPE][J], so, 0, 0);
     }
 };
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t tile_rsrc(const _Float16 *base, uint32_t first_row, uint32_t n_rows, int d) {
+    const uint32_t rows = first_row < n_rows ? min(n_rows - first_row, 256u) : 0u;
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16 *>(base + (size_t)first_row * d), 0, (int)(rows * (uint32_t)d * 2u),
+                                             0x00020000);
+}
+
+// v_max3_f32 without the canonicalisation (v_max_f32 x, x) hipcc puts in front of every fmaxf operand it cannot prove quiet.
+// NaN operands lose against numbers, like fmaxf.  The caller pads the MFMA -> VALU hazard of the first use.
+__device__ __forceinline__ float max3_f32(float a, float b, float c) {
+    float r;
+    asm volatile("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
 
 __device__ __forceinline__ float load_thr(const float *p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+#define STAMP(acc)                                      \
+    if constexpr (STAMPS) {                             \
+        const unsigned long long now_ = wall_clock64(); \
+        acc += now_ - t_last;                           \
+        t_last = now_;                                  \
+    }
+
+template <bool STAMPS>
 __global__ void __launch_bounds__(F_THREADS, 2) ip_topk_fast_kernel(const FastParams P) {
     extern __shared__ __attribute__((aligned(16))) float smem_f[];
     _Float16 *smem = reinterpret_cast<_Float16 *>(smem_f);
@@ -444,7 +489,7 @@ __global__ void __launch_bounds__(F_THREADS, 2) ip_topk_fast_kernel(const FastPa
 
     const int tid = threadIdx.x;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int l = tid & 63, g = l >> 5, i = l & 31;
+    const int l = tid & 63;
     const int wm = w >> 2, wn = w & 3;  // wave tile: 128 queries x 64 passages
     const uint32_t q0 = (uint32_t)qt * FQ;
     const int d = P.d;
@@ -473,34 +518,59 @@ __global__ void __launch_bounds__(F_THREADS, 2) ip_topk_fast_kernel(const FastPa
     // Tile sequence: window by window, inside a window the Ws tiles of this split.  K-tile index t of the tile
     // being computed; t >= NK addresses the next tile of the sequence, so the LDS-DMA prefetch (5-6 phases
     // ahead) runs through the filter step into the next tile.
-    Pipe256T<FastSrc> pipe;
+    Pipe256T<FastSrc, false, true, true> pipe;  // coarse schedule (two phases per K-tile, B-half0 fragments kept in registers)
     pipe.init(smem, w, l);
     {
         FastSrc &S = pipe.S;
-        S.q2 = P.q2; S.x2 = P.x2; S.d = d; S.n_last = n - 1; S.NK = d / FK;
-        S.w = w; S.rs = l >> 3;
-        S.ch = pipe_stage_chunk(pipe_stage_row(w, l, 0), l);  // rows of piece 1 are 64 further: same swizzle
+        S.NK = d / FK;
+        S.rq = tile_rsrc(P.q2, q0, P.nq, d);
+        const int ch = pipe_stage_chunk(pipe_stage_row(w, l, 0), l);  // rows of piece 1 are 64 further: same swizzle
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int r = pipe_stage_row(w, l, j);
-                S.qoff[h][j] = min(q0 + (uint32_t)pipe_a_tile_row(h, r), P.nq - 1) * (uint32_t)d + S.ch;
+                S.voff[h][j] = (uint32_t)(pipe_a_tile_row(h, r) * d + ch) * 2u;
+                S.voff[2 + h][j] = (uint32_t)(pipe_b_tile_row(h, r) * d + ch) * 2u;
             }
     }
     const int NK = d / FK;
-    int *epoch_s = cnt_s + FQ;  // last tile (1-based) in which some wave asked for a prune
+    // Per-query prune trigger.  The filter threshold is only as fresh as the last prune, and for most of the scan the
+    // insertion rate is (rows kept at the last prune) / (rows seen at the last prune) per row: waiting for a full buffer
+    // (1,792 rows) lets the rows seen grow 6.6x between prunes and has ~1 insertion per (wave, query group) per tile.
+    // Pruning when the buffer has doubled keeps the threshold within 2x of fresh at ~13 prunes per list.
+    int *trig_s = cnt_s + FQ;
+    int *epoch_s = trig_s + FQ;  // last tile (1-based) in which some wave asked for a prune
+    if (tid < FQ) trig_s[tid] = min(F_C - FP, P.prune_at);
     if (tid == 0) *epoch_s = 0;
+
+    // tiles of this split / of split 0 (the longest sequence) over the whole scan: the tile-step counter of the XCD
+    // group must see the same number of arrivals from every member
+    unsigned T_mine = 0, T_first = 0, n_in_grp = 0, step = 0;
+    if (P.tile_sync) {
+        const int last0 = (n_win - 1) * W;
+        auto tiles_of = [&](int sp) {
+            const int rest = n_tiles - last0 - sp * P.Ws;
+            return (unsigned)((n_win - 1) * P.Ws + (rest < 0 ? 0 : (rest < P.Ws ? rest : P.Ws)));
+        };
+        T_mine = tiles_of(split);
+        T_first = tiles_of(0);
+        const int q_in_grp = min(gq, P.n_qt - grp * gq);
+        n_in_grp = (unsigned)(q_in_grp * P.S);
+    }
+    unsigned long long t_last = 0, a_main = 0, a_filter = 0, a_prune = 0, a_sync = 0, a_end = 0, a_pro = 0;
+    if constexpr (STAMPS) t_last = wall_clock64();
 
     int t = split * P.Ws, jw = 0, win = 0;
     bool have = t < n_tiles;
     if (have) {
-        pipe.S.p0 = (uint32_t)t * FP;
-        pipe.S.p1 = pipe.S.p0;
+        pipe.S.rx0 = tile_rsrc(P.x2, (uint32_t)t * FP, n, d);
+        pipe.S.rx1 = pipe.S.rx0;
         pipe.prologue();  // also publishes thr_s / cnt_s / eps2_s / epoch_s
     } else {
         __syncthreads();
     }
+    STAMP(a_pro)
 
     while (have) {
         int tn, jn = jw + 1, winn = win;
@@ -513,8 +583,8 @@ __global__ void __launch_bounds__(F_THREADS, 2) ip_topk_fast_kernel(const FastPa
         }
         const bool have_n = tn < n_tiles;
         const uint32_t p0 = (uint32_t)t * FP;
-        pipe.S.p0 = p0;
-        pipe.S.p1 = (uint32_t)tn * FP;
+        pipe.S.rx0 = tile_rsrc(P.x2, p0, n, d);
+        pipe.S.rx1 = tile_rsrc(P.x2, (uint32_t)tn * FP, n, d);
         f32x16 acc[2][4];
 #pragma unroll
         for (int x = 0; x < 2; ++x)
@@ -524,33 +594,52 @@ __global__ void __launch_bounds__(F_THREADS, 2) ip_topk_fast_kernel(const FastPa
         if (have_n) pipe.tiles_streaming(NK, acc);
         else pipe.tiles_final(NK, acc);
         pipe.leave();
+        STAMP(a_main)
 
         // ---- filter: keep every row whose approximate score is within 2 eps of the k-th best -------
         // acc[x][y][r]: passage = p0 + wn*64 + x*32 + (r&3) + 8 (r>>2) + 4 g ; query = q0 + wm*128 + y*32 + i
-        const uint32_t pw0 = p0 + wn * 64 + 4 * g;
-        const bool ragged = p0 + FP > n;  // uniform: rows past n were staged as copies of row n-1
+        // (the lane id is laundered through an empty asm: hipcc otherwise hoists every lane-derived address of this
+        // section out of the tile loop, runs out of registers and reloads them from scratch here -- and a scratch
+        // reload is a vmcnt(0) wait that drains the LDS-DMA prefetch of the next tile)
+        int lf = l;
+        asm volatile("" : "+v"(lf));
+        const int gf = lf >> 5, qf = wm * 128 + (lf & 31);
+        const uint32_t pw0 = p0 + wn * 64 + 4 * gf;
+        const bool ragged = p0 + FP > n;  // uniform: rows past n were staged as zeros
+        // MFMA results -> VALU reads inside asm statements: the compiler does not pad that hazard for us
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int y = 0; y < 4; ++y) {
-            const int ql = wm * 128 + y * 32 + i;
+            const int ql = qf + y * 32;
             const bool qv = (q0 + ql) < P.nq;
             const float thr = thr_s[ql];  // -inf until the first prune
-            // Once the threshold is set almost no row passes (about k + band of 8.8 M per query): take the
-            // maximum of the lane's 32 scores first and skip the whole group when no lane of the wave has
-            // a candidate -- 16 v_max3 instead of 32 compare-and-branch sequences.  Scores are finite
-            // (fp16_ok above), so the maximum loses nothing.  Not on a ragged last tile (clamped rows).
+            // Once the threshold is set few rows pass: take the maximum of the lane's 32 scores first and skip the whole
+            // group when no lane of the wave has a candidate.  Scores are finite (fp16_ok above), so the maximum loses
+            // nothing.  Not on a ragged last tile (clamped rows).  Quarter maxima (8 scores each) come out of the same
+            // max tree (v_max3_f32: 18 instructions per 32 scores): the per-score compare-and-insert code only runs for
+            // the quarters that hold a candidate somewhere in the wave.
+            float mq[4];
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) {
+                const int x = qd >> 1, rb = (qd & 1) * 8;
+                float m = max3_f32(acc[x][y][rb], acc[x][y][rb + 1], acc[x][y][rb + 2]);
+                m = max3_f32(m, acc[x][y][rb + 3], acc[x][y][rb + 4]);
+                m = max3_f32(m, acc[x][y][rb + 5], acc[x][y][rb + 6]);
+                mq[qd] = max3_f32(m, acc[x][y][rb + 7], acc[x][y][rb + 7]);
+            }
             if (!ragged) {
-                float mx = acc[0][y][0];
-#pragma unroll
-                for (int r = 1; r < 16; ++r) mx = fmaxf(mx, acc[0][y][r]);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, acc[1][y][r]);
+                const float mx = max3_f32(max3_f32(mq[0], mq[1], mq[2]), mq[3], mq[3]);
                 if (__ballot(qv && !(mx < thr)) == 0ull) continue;
             }
             u64 *cq = cand + (size_t)ql * F_C;
 #pragma unroll
-            for (int x = 0; x < 2; ++x)
+            for (int qd = 0; qd < 4; ++qd) {
+                if (!ragged && __ballot(qv && !(mq[qd] < thr)) == 0ull) continue;
+                const int x = qd >> 1, rb = (qd & 1) * 8;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
+                for (int r = rb; r < rb + 8; ++r) {
                     const uint32_t prow = pw0 + x * 32 + (r & 3) + 8 * (r >> 2);
                     const float sc = acc[x][y][r];
                     if (qv && prow < n && !(sc < thr)) {
@@ -558,6 +647,7 @@ __global__ void __launch_bounds__(F_THREADS, 2) ip_topk_fast_kernel(const FastPa
                         cq[sl] = pack_key(sc, prow);
                     }
                 }
+            }
         }
         // ---- prune buffers that could overflow on the next tile (approximate keys) --------------------
         // Barriers here are raw s_barriers: a __syncthreads would drain the LDS-DMA prefetch of the next
@@ -565,24 +655,31 @@ __global__ void __launch_bounds__(F_THREADS, 2) ip_topk_fast_kernel(const FastPa
         // the scan) do all waves retire their candidate stores before anybody reads them back.
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+        STAMP(a_filter)
         {
-            const int c32 = cnt_s[w * 32 + (l & 31)];
-            if (__ballot(c32 > F_C - FP) != 0ull && l == 0) *epoch_s = t + 1;
+            const int c32 = cnt_s[w * 32 + (l & 31)], g32 = trig_s[w * 32 + (l & 31)];
+            if (__ballot(c32 > g32) != 0ull && l == 0) *epoch_s = t + 1;
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         if (*epoch_s == t + 1) {  // block-uniform
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
-            for (int qq = 0; qq < 32; ++qq) {
+            int lp = l;  // laundered like lf above: keeps the 32 buffer positions j * 64 + lane out of the tile loop's registers
+            asm volatile("" : "+v"(lp));
+            // queries of this wave whose buffer passed its trigger (lane q < 32 looks at query w * 32 + q)
+            u64 need = __ballot(lp < 32 && cnt_s[w * 32 + (lp & 31)] > trig_s[w * 32 + (lp & 31)]);
+            while (need) {
+                const int qq = __builtin_ctzll(need);
+                need &= need - 1;
                 const int ql = w * 32 + qq;
                 const int n_c = __builtin_amdgcn_readfirstlane(cnt_s[ql]);
-                if (n_c > F_C - FP) {
+                {
                     u64 *cq = cand + (size_t)ql * F_C;
                     u64 keys[F_NPL];
 #pragma unroll
                     for (int j = 0; j < F_NPL; ++j) {
-                        const int idx = j * 64 + l;
+                        const int idx = j * 64 + lp;
                         keys[j] = (idx < n_c) ? cq[idx] : 0ull;
                     }
                     u64 T = 0;  // k-th largest approximate key
@@ -595,14 +692,14 @@ __global__ void __launch_bounds__(F_THREADS, 2) ip_topk_fast_kernel(const FastPa
                     }
                     float thr_new = key_score(T) - eps2_s[ql];
                     if (P.share) {  // what the other splits of this query have established is just as valid here
-                        float o = (l < P.S && l != split) ? load_thr(thr_tile + (size_t)l * FQ + ql) : -INFINITY;
+                        float o = (lp < P.S && lp != split) ? load_thr(thr_tile + (size_t)lp * FQ + ql) : -INFINITY;
 #pragma unroll
                         for (int off = 16; off > 0; off >>= 1) o = fmaxf(o, __shfl_xor(o, off));  // S <= 32; NaN = none
                         o = __shfl(o, 0);
                         thr_new = fmaxf(thr_new, o);
                     }
                     int base = 0;
-                    const u64 lt_mask = (1ull << l) - 1ull;
+                    const u64 lt_mask = (1ull << lp) - 1ull;
 #pragma unroll
                     for (int j = 0; j < F_NPL; ++j) {
                         const bool keep = keys[j] != 0ull && !(key_score(keys[j]) < thr_new);
@@ -610,7 +707,7 @@ __global__ void __launch_bounds__(F_THREADS, 2) ip_topk_fast_kernel(const FastPa
                         if (keep) cq[base + __popcll(m & lt_mask)] = keys[j];
                         base += __popcll(m);
                     }
-                    if (l == 0) {
+                    if (lp == 0) {
                         if (base > F_C - FP) {  // more than 1,792 rows inside one 2 eps band: this query is redone exactly
                             if (atomicExch(&P.ovf_flag[q0 + ql], 1) == 0) {
                                 const int slot = atomicAdd(&P.ctl->ovf_count, 1);
@@ -619,11 +716,32 @@ __global__ void __launch_bounds__(F_THREADS, 2) ip_topk_fast_kernel(const FastPa
                             base = F_C - FP;
                         }
                         cnt_s[ql] = base;
+                        trig_s[ql] = min(F_C - FP, max(2 * base, base + 128));
                         thr_s[ql] = thr_new;
                         if (P.share) __hip_atomic_store(thr_mine + ql, thr_new, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
                 }
             }
+        }
+        STAMP(a_prune)
+        // ---- tile step of the XCD group: the 32 workgroups that share this XCD's L2 stay on the same tile step, so
+        // that a K-slice of a query / corpus tile is still in the L2 when its other readers ask for it ---------------
+        if (P.tile_sync) {
+            if (tid == 0) {
+                __hip_atomic_fetch_add(&P.grp_ctr[grp], have_n ? 1u : 1u + (T_first - T_mine), __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+                if (have_n) {
+                    const unsigned target = (step + 1) * n_in_grp;
+                    const unsigned long long t_in = wall_clock64();
+                    while (__hip_atomic_load(&P.grp_ctr[grp], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+                        __builtin_amdgcn_s_sleep(8);
+                        if (wall_clock64() - t_in > P.tile_wait_ticks) break;
+                    }
+                }
+            }
+            ++step;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
         }
         // ---- window boundary: wait (bounded) for the other workgroups, adopt their thresholds ----------
         if (winn != win && winn < n_win) {  // block-uniform
@@ -649,79 +767,119 @@ __global__ void __launch_bounds__(F_THREADS, 2) ip_topk_fast_kernel(const FastPa
         }
         // thr_s / cnt_s updates are published by the barriers of the next tile's main loop
         t = tn; jw = jn; win = winn; have = have_n;
+        STAMP(a_sync)
     }
     __syncthreads();
 
-    // ---- block end: final band prune, exact re-scoring of the band, exact top-k of the split -----------
-    // A buffer ends the scan with 700-1,700 rows (everything above the LAST threshold), but only the rows
-    // within 2 eps of the final k-th best approximate score (about k + 66) can be in the exact top-k.
-    // Re-scoring costs a 3 KB row read each, so the band is cut first: the k-th approximate key by the
-    // same radix select, the survivors' buffer positions compacted into an LDS list (dense: every lane
-    // re-scores one row per round), exact keys kept in registers and selected from there.
-    float *qrow_lds = smem_f + w * (d + F_C / 2);  // per wave in the idle stage area: d floats + 4 KiB of positions
+    // ---- hand the lists to rescore_kernel: rows buffered, final threshold --------------------------------------
+    if (tid < FQ) {
+        P.cnt_g[((size_t)qt * P.S + split) * FQ + tid] = cnt_s[tid];
+        thr_mine[tid] = thr_s[tid];  // (thr_g doubles as the final-threshold array: nobody reads it during the scan any more
+                                     //  once every split of this query tile is done, and a stale read is only a weaker bound)
+    }
+    if constexpr (STAMPS) {
+        STAMP(a_end)
+        if (tid == 0) {
+            unsigned long long *o = P.stamps + (size_t)blockIdx.x * 8;
+            o[0] = a_pro; o[1] = a_main; o[2] = a_filter; o[3] = a_prune; o[4] = a_sync; o[5] = a_end;
+            o[6] = (unsigned long long)qt << 32 | (unsigned)split;
+            o[7] = __builtin_amdgcn_s_getreg(0x1814) /* XCC_ID */;
+        }
+    }
+}
+
+// ---- exact re-scoring of the lists the filter kernel left: one wave per (query, split) ---------------------------------
+// A buffer ends the scan with a few hundred rows (everything above the LAST threshold), but only the rows within 2 eps
+// of the final k-th best approximate score (about k + 66) can be in the exact top-k.  Re-scoring costs a 3 KB row read
+// each, so the band is cut first: the k-th approximate key by radix select, the survivors' buffer positions compacted
+// into an LDS list (dense: every lane re-scores one row per round), exact keys kept in registers and selected from there.
+// Its own kernel: the gathers are latency-bound and the filter kernel has neither the registers nor the waves to hide them.
+struct RescoreParams {
+    const float *q32, *x32, *qnorm;
+    const DedupHeader *hdr;
+    const uint32_t *live2row;
+    const u64 *cand;     // [n_qt * S][FQ][F_C]
+    const int *cnt_g;    // [n_qt * S][FQ]
+    const float *thr_g;  // [n_qt * S][FQ] final filter thresholds
+    u64 *part;           // [nq][S][k]
+    uint32_t nq;
+    int d, k, S;
+    float slack_rel, slack_abs;
+};
+
+__global__ void __launch_bounds__(256, 2) rescore_kernel(const RescoreParams P) {
+    extern __shared__ __attribute__((aligned(16))) float rs_smem[];
+    const int l = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int d = P.d;
+    float *qrow_lds = rs_smem + w * (d + F_C / 2);  // d floats + 4 KiB of buffer positions per wave
     unsigned short *list = reinterpret_cast<unsigned short *>(qrow_lds + d);
+    // list id -> (query tile, split, query): lists of one query tile and split are consecutive
+    const size_t lid = (size_t)blockIdx.x * 4 + w;
+    const int ql = (int)(lid % FQ);
+    const size_t ts = lid / FQ;  // qt * S + split
+    const int split = (int)(ts % P.S);
+    const uint32_t qg = (uint32_t)(ts / P.S) * FQ + ql;
+    if (qg >= P.nq) return;  // wave-uniform
+    const int n_c = P.cnt_g[lid];
+    const u64 *cq = P.cand + lid * (size_t)F_C;
+    u64 *dst = P.part + ((size_t)qg * P.S + split) * (size_t)P.k;
+    const float *qsrc = P.q32 + (size_t)qg * d;
+    for (int k4 = l * 4; k4 < d; k4 += 256) *reinterpret_cast<f32x4 *>(qrow_lds + k4) = *reinterpret_cast<const f32x4 *>(qsrc + k4);
+    const float qn = P.qnorm[qg], xm = __builtin_bit_cast(float, P.hdr->xmax_bits);
+    const bool fp16_ok = qn <= 65504.0f && xm <= 65504.0f;
+    const float eps2 = fp16_ok ? 2.0f * (P.slack_rel * qn * xm + P.slack_abs * (qn + xm)) : INFINITY;  // as in the filter kernel
     const u64 lt_mask = (1ull << l) - 1ull;
-    for (int qq = 0; qq < 32; ++qq) {
-        const int ql = w * 32 + qq;
-        const uint32_t qg = q0 + ql;
-        if (qg >= P.nq) continue;  // wave-uniform
-        const int n_c = __builtin_amdgcn_readfirstlane(cnt_s[ql]);
-        const u64 *cq = cand + (size_t)ql * F_C;
-        u64 *dst = P.part + ((size_t)qg * P.S + split) * (size_t)P.k;
-        const float *qsrc = P.q32 + (size_t)qg * d;
-        for (int k4 = l * 4; k4 < d; k4 += 256) *reinterpret_cast<f32x4 *>(qrow_lds + k4) = *reinterpret_cast<const f32x4 *>(qsrc + k4);
-        u64 keys[F_NPL];
+    u64 keys[F_NPL];
+#pragma unroll
+    for (int j = 0; j < F_NPL; ++j) {
+        const int idx = j * 64 + l;
+        keys[j] = (idx < n_c) ? cq[idx] : 0ull;
+    }
+    float thr_band = P.thr_g[lid];  // rows buffered before the threshold rose (own prunes, other splits) are out as well
+    if (!(thr_band == thr_band)) thr_band = -INFINITY;
+    if (n_c > P.k) {
+        u64 T = 0;  // k-th largest approximate key
+        for (int bit = 63; bit >= 0; --bit) {
+            const u64 t2 = T | (1ull << bit);
+            int ge = 0;
+#pragma unroll
+            for (int j = 0; j < F_NPL; ++j) ge += __popcll(__ballot(keys[j] >= t2));
+            if (ge >= P.k) T = t2;
+        }
+        thr_band = fmaxf(thr_band, key_score(T) - eps2);
+    }
+    int n_band = 0;
+#pragma unroll
+    for (int j = 0; j < F_NPL; ++j) {
+        const bool keep = keys[j] != 0ull && !(key_score(keys[j]) < thr_band);
+        const u64 m = __ballot(keep);
+        if (keep) list[n_band + __popcll(m & lt_mask)] = (unsigned short)(j * 64 + l);
+        n_band += __popcll(m);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // exact keys, dense: round r, lane l re-scores list entry 64 r + l
+#pragma unroll
+    for (int j = 0; j < F_NPL; ++j) keys[j] = 0ull;
+    for (int r = 0; r * 64 < n_band; ++r) {
+        const int e = r * 64 + l;
+        u64 v = 0ull;
+        if (e < n_band) {
+            const uint32_t prow = P.live2row[key_row(cq[list[e]])];  // image row -> shard row
+            v = pack_key(exact_ip_lds(qrow_lds, P.x32 + (size_t)prow * d, d), prow);
+        }
+#pragma unroll
+        for (int j = 0; j < F_NPL; ++j) keys[j] = (j == r) ? v : keys[j];  // r is wave-uniform: register file stays static
+    }
+    if (n_band > P.k) {
+        float tau_new;
+        select_topk_regs<F_NPL>(keys, P.k, dst, &tau_new);
+    } else {
 #pragma unroll
         for (int j = 0; j < F_NPL; ++j) {
-            const int idx = j * 64 + l;
-            keys[j] = (idx < n_c) ? cq[idx] : 0ull;
+            const int e = j * 64 + l;
+            if (e < P.k) dst[e] = keys[j];
         }
-        float thr_band = thr_s[ql];  // rows buffered before the threshold rose (own prunes, other splits) are out as well
-        if (n_c > P.k) {
-            u64 T = 0;  // k-th largest approximate key
-            for (int bit = 63; bit >= 0; --bit) {
-                const u64 t2 = T | (1ull << bit);
-                int ge = 0;
-#pragma unroll
-                for (int j = 0; j < F_NPL; ++j) ge += __popcll(__ballot(keys[j] >= t2));
-                if (ge >= P.k) T = t2;
-            }
-            thr_band = fmaxf(thr_band, key_score(T) - eps2_s[ql]);
-        }
-        int n_band = 0;
-#pragma unroll
-        for (int j = 0; j < F_NPL; ++j) {
-            const bool keep = keys[j] != 0ull && !(key_score(keys[j]) < thr_band);
-            const u64 m = __ballot(keep);
-            if (keep) list[n_band + __popcll(m & lt_mask)] = (unsigned short)(j * 64 + l);
-            n_band += __popcll(m);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        // exact keys, dense: round r, lane l re-scores list entry 64 r + l
-#pragma unroll
-        for (int j = 0; j < F_NPL; ++j) keys[j] = 0ull;
-        for (int r = 0; r * 64 < n_band; ++r) {
-            const int e = r * 64 + l;
-            u64 v = 0ull;
-            if (e < n_band) {
-                const uint32_t prow = P.live2row[key_row(cq[list[e]])];  // image row -> shard row
-                v = pack_key(exact_ip_lds(qrow_lds, P.x32 + (size_t)prow * d, d), prow);
-            }
-#pragma unroll
-            for (int j = 0; j < F_NPL; ++j) keys[j] = (j == r) ? v : keys[j];  // r is wave-uniform: register file stays static
-        }
-        if (n_band > P.k) {
-            float tau_new;
-            select_topk_regs<F_NPL>(keys, P.k, dst, &tau_new);
-        } else {
-#pragma unroll
-            for (int j = 0; j < F_NPL; ++j) {
-                const int e = j * 64 + l;
-                if (e < P.k) dst[e] = keys[j];
-            }
-        }
-        __builtin_amdgcn_wave_barrier();  // the next query reuses qrow_lds and list
     }
 }
 
@@ -749,7 +907,7 @@ __global__ void __launch_bounds__(256) gather_overflow_kernel(FastCtl *ctl, cons
 struct FastPlan {
     int S, Ws;
     int64_t qc;  // queries per launch
-    size_t q2_bytes, qn_bytes, cand_bytes, part_bytes, thr_bytes, flag_bytes, qfb_bytes, fbk_bytes, fb_bytes, fball_bytes;
+    size_t q2_bytes, qn_bytes, cand_bytes, part_bytes, thr_bytes, cnt_bytes, flag_bytes, qfb_bytes, fbk_bytes, fb_bytes, fball_bytes;
 };
 
 int env_int(const char *name, int dflt) {
@@ -784,7 +942,8 @@ bool make_fast_plan(int64_t n, int64_t nq, int d, int k, FastPlan *pl) {
     pl->cand_bytes = (size_t)qct * S * FQ * F_C * sizeof(u64);
     pl->part_bytes = align_up((size_t)pl->qc * S * k * sizeof(u64), 256);
     pl->thr_bytes = align_up((size_t)qct * S * FQ * sizeof(float) + (size_t)pl->qc * sizeof(int), 256);  // thr_g + fb_slot (0xFF fill)
-    pl->flag_bytes = align_up(256 + (size_t)pl->qc * sizeof(int) + OVF_CAP * sizeof(int), 256);           // ctl + ovf_flag + ovf_list (0 fill)
+    pl->cnt_bytes = align_up((size_t)qct * S * FQ * sizeof(int), 256);
+    pl->flag_bytes = align_up(256 + (size_t)pl->qc * sizeof(int) + OVF_CAP * sizeof(int) + 1024 * sizeof(int), 256);  // ctl + ovf_flag + ovf_list + grp_ctr (0 fill)
     pl->qfb_bytes = align_up((size_t)OVF_CAP * d * sizeof(float), 256);
     pl->fbk_bytes = align_up((size_t)OVF_CAP * k * sizeof(u64), 256);
     const int64_t nqc = nq < pl->qc ? nq : pl->qc;
@@ -794,11 +953,17 @@ bool make_fast_plan(int64_t n, int64_t nq, int d, int k, FastPlan *pl) {
 }
 
 size_t fast_search_bytes(const FastPlan &pl) {
-    return 256 + pl.q2_bytes + pl.qn_bytes + pl.part_bytes + pl.cand_bytes + pl.thr_bytes + pl.flag_bytes + pl.qfb_bytes +
+    return 256 + pl.q2_bytes + pl.qn_bytes + pl.part_bytes + pl.cand_bytes + pl.thr_bytes + pl.cnt_bytes + pl.flag_bytes + pl.qfb_bytes +
            pl.fbk_bytes + pl.fb_bytes + pl.fball_bytes;
 }
 
+unsigned long long *g_fast_stamps = nullptr;
+
 }  // namespace
+
+// measurement hook: while d_stamps != NULL the filter kernel is the instrumented build and every workgroup of the LAST launch
+// chunk leaves uint64[8] = {prologue, main loop, filter, prune, sync, block end} ticks of the 100 MHz counter, (qt << 32 | split), XCC id
+void set_fast_stamps(unsigned long long *d_stamps) { g_fast_stamps = d_stamps; }
 
 // ---- search image --------------------------------------------------------------------------------------
 size_t ip_index_bytes(int64_t n, int d) {
@@ -864,6 +1029,7 @@ int ip_topk_fast(const float *d_x, int64_t n, int64_t row_base, const void *d_in
     u64 *part = reinterpret_cast<u64 *>(p); p += pl.part_bytes;
     u64 *cand = reinterpret_cast<u64 *>(p); p += pl.cand_bytes;
     char *ff_area = p; p += pl.thr_bytes;    // 0xFF-filled per chunk
+    int *cnt_g = reinterpret_cast<int *>(p); p += pl.cnt_bytes;
     char *zero_area = p; p += pl.flag_bytes;  // zero-filled per chunk
     float *qfb = reinterpret_cast<float *>(p); p += pl.qfb_bytes;
     u64 *fb_keys = reinterpret_cast<u64 *>(p); p += pl.fbk_bytes;
@@ -889,7 +1055,9 @@ int ip_topk_fast(const float *d_x, int64_t n, int64_t row_base, const void *d_in
 
     static bool attr_done = false;
     if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(ip_topk_fast_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(ip_topk_fast_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)F_LDS_BYTES) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void *>(ip_topk_fast_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)F_LDS_BYTES) != hipSuccess)
             return check_launch("ip_topk_fast attr");
         attr_done = true;
@@ -898,6 +1066,10 @@ int ip_topk_fast(const float *d_x, int64_t n, int64_t row_base, const void *d_in
     const float slack_abs = 1.25f * 5.9604645e-8f * sqrtf((float)d);
     const int share = env_int("ANCE_FAST_SHARE", 1);
     const int wait_us = env_int("ANCE_FAST_WINDOW_WAIT_US", 200);
+    const int prune_at = env_int("ANCE_FAST_PRUNE_AT", 512);
+    const int tile_sync = env_int("ANCE_FAST_TILE_SYNC", 0);
+    const int tile_wait_us = env_int("ANCE_FAST_TILE_WAIT_US", 30);
+    unsigned long long *stamps = g_fast_stamps;  // measurement hook (ance_debug_search_stamps)
     for (int64_t q0 = 0; q0 < nq; q0 += pl.qc) {
         const int64_t nqc = (nq - q0) < pl.qc ? (nq - q0) : pl.qc;
         (void)hipMemsetAsync(ff_area, 0xFF, pl.thr_bytes, st);
@@ -914,13 +1086,26 @@ int ip_topk_fast(const float *d_x, int64_t n, int64_t row_base, const void *d_in
         P.n_qt = (int)((nqc + FQ - 1) / FQ);
         P.share = share && pl.S > 1; P.wait_ticks = (unsigned)(wait_us > 0 ? wait_us * 100 : 0);
         P.slack_rel = slack_rel; P.slack_abs = slack_abs; P.cand = cand; P.part = part; P.thr_g = thr_g; P.ctl = ctl;
-        P.ovf_flag = ovf_flag; P.ovf_list = ovf_list;
+        P.ovf_flag = ovf_flag; P.ovf_list = ovf_list; P.cnt_g = cnt_g;
+        P.grp_ctr = reinterpret_cast<unsigned int *>(ovf_list + OVF_CAP);
+        P.prune_at = prune_at > k + 64 ? prune_at : k + 64;
+        P.tile_sync = tile_sync; P.tile_wait_ticks = (unsigned)(tile_wait_us > 0 ? tile_wait_us * 100 : 0);
+        P.stamps = stamps;
         const int gq = 32 / pl.S;
         const int groups = (P.n_qt + gq - 1) / gq;
         const unsigned blocks = (unsigned)((groups + 7) / 8 * 8) * 32u;
         {
             ProfScope ps(PC_SCAN, st, 2.0 * (double)nqc * (double)n * (double)d);
-            hipLaunchKernelGGL(ip_topk_fast_kernel, dim3(blocks), dim3(F_THREADS), F_LDS_BYTES, st, P);
+            if (stamps) hipLaunchKernelGGL(ip_topk_fast_kernel<true>, dim3(blocks), dim3(F_THREADS), F_LDS_BYTES, st, P);
+            else hipLaunchKernelGGL(ip_topk_fast_kernel<false>, dim3(blocks), dim3(F_THREADS), F_LDS_BYTES, st, P);
+        }
+        {
+            RescoreParams R;
+            R.q32 = P.q32; R.x32 = d_x; R.qnorm = qn; R.hdr = H; R.live2row = P.live2row; R.cand = cand; R.cnt_g = cnt_g; R.thr_g = thr_g;
+            R.part = part; R.nq = P.nq; R.d = d; R.k = k; R.S = pl.S; R.slack_rel = slack_rel; R.slack_abs = slack_abs;
+            const size_t lds = (size_t)4 * (d + F_C / 2) * sizeof(float);
+            ProfScope ps(PC_RESCORE, st);
+            hipLaunchKernelGGL(rescore_kernel, dim3((unsigned)(P.n_qt * pl.S * FQ / 4)), dim3(256), lds, st, R);
         }
         // queries whose buffers overflowed: redone by the exact scan, one by one (<= OVF_CAP) or as a whole chunk
         hipLaunchKernelGGL(gather_overflow_kernel, dim3(OVF_CAP), dim3(256), 0, st, ctl, ovf_list, d_q + (size_t)q0 * d, d, qfb, fb_slot);

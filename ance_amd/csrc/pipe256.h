@@ -70,10 +70,14 @@ struct PipeSrcFixed {
     __device__ __forceinline__ const _Float16 *addr(int t) const {
         return src[TYPE][J] + ((dbg & 1) ? (t & 1) * 64 : t * 64);
     }
+    template <int TYPE, int J>
+    __device__ __forceinline__ void issue(int t, pipe_lds_t *dst) const {
+        __builtin_amdgcn_global_load_lds((pipe_glb_t *)addr<TYPE, J>(t), dst, 16, 0, 0);
+    }
 };
 
-// SRC provides  template <int TYPE, int J> const _Float16 *addr(int t)  : the per-lane source address of
-// piece J of half-tile TYPE (0 A-half0, 1 A-half1, 2 B-half0, 3 B-half1) of K-tile t.
+// SRC provides  template <int TYPE, int J> void issue(int t, pipe_lds_t *dst)  : the LDS-DMA (16 bytes per lane, 1 KiB per
+// wave, lane-linear at dst) of piece J of half-tile TYPE (0 A-half0, 1 A-half1, 2 B-half0, 3 B-half1) of K-tile t.
 // DBG compiles measurement ablations in (dbg bit 1: no MFMA, bit 3: no staging); product code uses DBG = false.
 // KEEP_B0: hold the B-half0 fragments of a K-tile in 16 more VGPRs from phase c0 to c3 instead of reading
 // them from LDS a second time (the GEMM has the registers, the search filter does not).
@@ -111,7 +115,7 @@ struct Pipe256T {
     __device__ __forceinline__ void stage_piece(int t) {
         if (DBG && (dbg & 8)) return;            // ablation: stage nothing (prologue included)
         _Float16 *dst = smem + (t & 1) * PIPE_BUF_HALVES + TYPE * PIPE_HALF_HALVES + (w + 8 * J) * 512;
-        __builtin_amdgcn_global_load_lds((pipe_glb_t *)S.template addr<TYPE, J>(t), (pipe_lds_t *)dst, 16, 0, 0);
+        S.template issue<TYPE, J>(t, (pipe_lds_t *)dst);
     }
     template <int TYPE>
     __device__ __forceinline__ void stage(int t) {

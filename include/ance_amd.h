@@ -50,9 +50,10 @@ const char *ance_last_error(void);
  * launch count, then keeps accumulating.  Categories, in order:
  *   0 plan/pack  1 embed+LN  2 gemm Q|K  3 gemm V^T  4 attention  5 gemm attn-out  6 LayerNorm
  *   7 gemm FFN1+GELU  8 gemm FFN2  9 head  10 ip_topk scan  11 top-k finalize/merge
+ *   12 exact re-scoring of the two-precision search
  * Returns the number of categories.  Not thread safe; off by default (no events are created).
  */
-#define ANCE_PROFILE_CATEGORIES 12
+#define ANCE_PROFILE_CATEGORIES 13
 void ance_profile_enable(int on);
 int ance_profile_read(double *ms, double *work, long long *count, int n);
 
@@ -216,6 +217,16 @@ int ance_encode_ids(AnceEncoder *enc, const int32_t *d_ids, int64_t ld_ids, cons
  */
 int ance_debug_gemm(int ablate, int epi, const void *d_a_f16, const void *d_b_f16, int M, int N, int K,
                     const float *d_bias, void *d_out, const float *d_res32, void *stream);
+
+/*
+ * Measurement hook of the two-precision search: while d_stamps != NULL, the filter kernel runs as its instrumented
+ * build and every workgroup of a launch chunk leaves uint64[8] at d_stamps + 8 * blockIdx: ticks of the 100 MHz
+ * counter spent in {prologue, fp16 main loop, filter, prune, waits (tile step + window), block-end exact re-scoring},
+ * then (query tile << 32 | split) and the XCC id it ran on.  The buffer needs 8 * 8 * 2048 bytes.  NULL switches it off.
+ * Also read at every call (tuning / A-B): ANCE_FAST_TILE_SYNC=1 keeps the workgroups of an XCD on the same corpus
+ * tile step (bounded wait ANCE_FAST_TILE_WAIT_US, default 30).
+ */
+void ance_debug_search_stamps(void *d_stamps);
 
 /* Introspection for tests / bench: algorithmic FLOPs of the last ance_encode_* call cannot be
  * known without a sync, so the library exposes the pure function instead:
