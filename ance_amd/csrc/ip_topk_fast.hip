@@ -388,42 +388,6 @@ struct FastParams {
     unsigned long long *stamps;  // measurement: [workgroup][8] accumulated 100 MHz ticks (STAMPS kernel only)
 };
 
-// exact score: fp32 fmaf chain over k ascending from +0 (== v_mfma_f32_32x32x2_f32, == the oracle).
-// q comes from LDS (every lane of the wave works on the same query: broadcast reads), x from global
-// memory with 16 independent 16-byte loads in flight per lane.
-__device__ __forceinline__ float exact_ip_lds(const float *q_lds, const float *x, int d) {
-    // d % 128 == 0.  Two 64-float batches in flight: the loads of the next batch are issued before the 64 dependent
-    // fmas of the current one, so only the first batch's memory latency is exposed.
-    float s = 0.0f;
-    f32x4 xa[16], xb[16];
-#pragma unroll
-    for (int j = 0; j < 16; ++j) xa[j] = *reinterpret_cast<const f32x4 *>(x + 4 * j);
-    for (int k0 = 0; k0 < d; k0 += 128) {
-#pragma unroll
-        for (int j = 0; j < 16; ++j) xb[j] = *reinterpret_cast<const f32x4 *>(x + k0 + 64 + 4 * j);
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const f32x4 a = *reinterpret_cast<const f32x4 *>(q_lds + k0 + 4 * j);
-            s = __builtin_fmaf(a[0], xa[j][0], s);
-            s = __builtin_fmaf(a[1], xa[j][1], s);
-            s = __builtin_fmaf(a[2], xa[j][2], s);
-            s = __builtin_fmaf(a[3], xa[j][3], s);
-        }
-        const int kn = k0 + 128 < d ? k0 + 128 : 0;  // (the last iteration re-reads the row's head: result unused)
-#pragma unroll
-        for (int j = 0; j < 16; ++j) xa[j] = *reinterpret_cast<const f32x4 *>(x + kn + 4 * j);
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const f32x4 a = *reinterpret_cast<const f32x4 *>(q_lds + k0 + 64 + 4 * j);
-            s = __builtin_fmaf(a[0], xb[j][0], s);
-            s = __builtin_fmaf(a[1], xb[j][1], s);
-            s = __builtin_fmaf(a[2], xb[j][2], s);
-            s = __builtin_fmaf(a[3], xb[j][3], s);
-        }
-    }
-    return s;
-}
-
 // Source policy of the streamed main loop (pipe256.h).  Both operands go through buffer descriptors (wave-uniform
 // SGPRs) + one 32-bit per-lane byte offset per staged piece that never changes during the kernel, + the K offset in an
 // SGPR: 8 address VGPRs in all.  (With flat 64-bit addresses hipcc keeps a pointer pair per piece for the current AND
@@ -788,12 +752,14 @@ __global__ void __launch_bounds__(F_THREADS, 2) ip_topk_fast_kernel(const FastPa
     }
 }
 
-// ---- exact re-scoring of the lists the filter kernel left: one wave per (query, split) ---------------------------------
+// ---- exact re-scoring of the lists the filter kernel left: one wave (= one workgroup) per (query, split) ---------------
 // A buffer ends the scan with a few hundred rows (everything above the LAST threshold), but only the rows within 2 eps
-// of the final k-th best approximate score (about k + 66) can be in the exact top-k.  Re-scoring costs a 3 KB row read
-// each, so the band is cut first: the k-th approximate key by radix select, the survivors' buffer positions compacted
-// into an LDS list (dense: every lane re-scores one row per round), exact keys kept in registers and selected from there.
-// Its own kernel: the gathers are latency-bound and the filter kernel has neither the registers nor the waves to hide them.
+// of the final k-th best approximate score (about k + 66) can be in the exact top-k.  The band is cut first: the k-th
+// approximate key by radix select, the survivors' buffer positions compacted into an LDS list.  Then, 64 rows per
+// round (one per lane), 256 floats of every row at a time: the wave copies the 64 row pieces into LDS with one
+// 1 KiB LDS-DMA each -- every lane reading its own row straight from memory made 64 scattered 16-byte requests per
+// load instruction and ran at 1.3 TB/s -- and each lane runs the canonical fmaf chain (k ascending) over its row's
+// piece from LDS (row stride 1040 bytes: conflict-free ds_read_b128).  Exact keys stay in registers for the selection.
 struct RescoreParams {
     const float *q32, *x32, *qnorm;
     const DedupHeader *hdr;
@@ -806,20 +772,24 @@ struct RescoreParams {
     int d, k, S;
     float slack_rel, slack_abs;
 };
+constexpr int RS_CHUNK = 256;            // floats of a row staged per step
+constexpr int RS_STRIDE = RS_CHUNK + 4;  // floats between the staged pieces of consecutive rows
+inline size_t rescore_lds_bytes(int d) { return ((size_t)d + F_C / 2 + 64 * RS_STRIDE) * sizeof(float); }
 
-__global__ void __launch_bounds__(256, 2) rescore_kernel(const RescoreParams P) {
+__global__ void __launch_bounds__(64) rescore_kernel(const RescoreParams P) {
     extern __shared__ __attribute__((aligned(16))) float rs_smem[];
-    const int l = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int l = threadIdx.x;
     const int d = P.d;
-    float *qrow_lds = rs_smem + w * (d + F_C / 2);  // d floats + 4 KiB of buffer positions per wave
-    unsigned short *list = reinterpret_cast<unsigned short *>(qrow_lds + d);
+    float *qrow_lds = rs_smem;                                                   // d floats
+    unsigned short *list = reinterpret_cast<unsigned short *>(qrow_lds + d);    // F_C buffer positions (4 KiB)
+    float *stage = qrow_lds + d + F_C / 2;                                       // 64 x RS_STRIDE floats
     // list id -> (query tile, split, query): lists of one query tile and split are consecutive
-    const size_t lid = (size_t)blockIdx.x * 4 + w;
+    const size_t lid = blockIdx.x;
     const int ql = (int)(lid % FQ);
     const size_t ts = lid / FQ;  // qt * S + split
     const int split = (int)(ts % P.S);
     const uint32_t qg = (uint32_t)(ts / P.S) * FQ + ql;
-    if (qg >= P.nq) return;  // wave-uniform
+    if (qg >= P.nq) return;
     const int n_c = P.cnt_g[lid];
     const u64 *cq = P.cand + lid * (size_t)F_C;
     u64 *dst = P.part + ((size_t)qg * P.S + split) * (size_t)P.k;
@@ -858,18 +828,43 @@ __global__ void __launch_bounds__(256, 2) rescore_kernel(const RescoreParams P) 
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    // exact keys, dense: round r, lane l re-scores list entry 64 r + l
 #pragma unroll
     for (int j = 0; j < F_NPL; ++j) keys[j] = 0ull;
-    for (int r = 0; r * 64 < n_band; ++r) {
-        const int e = r * 64 + l;
-        u64 v = 0ull;
-        if (e < n_band) {
-            const uint32_t prow = P.live2row[key_row(cq[list[e]])];  // image row -> shard row
-            v = pack_key(exact_ip_lds(qrow_lds, P.x32 + (size_t)prow * d, d), prow);
+    for (int r0 = 0, rnd = 0; r0 < n_band; r0 += 64, ++rnd) {
+        const int e = r0 + l;
+        const bool valid = e < n_band;
+        const uint32_t prow = valid ? P.live2row[key_row(cq[list[e]])] : 0u;  // image row -> shard row
+        const int rows = min(64, n_band - r0);  // wave-uniform
+        float sc = 0.0f;
+        for (int c0 = 0; c0 < d; c0 += RS_CHUNK) {
+            const int len = min(RS_CHUNK, d - c0);         // 256, or 128 for the last piece when d % 256 == 128
+            const int lsrc = l * 4 < len ? l * 4 : 0;      // lanes past a short piece re-read its head (never past the row)
+            for (int r = 0; r < rows; ++r) {
+                const uint32_t row = __builtin_amdgcn_readlane(prow, r);
+                const float *src = P.x32 + ((size_t)row * d + c0) + lsrc;
+                __builtin_amdgcn_global_load_lds((pipe_glb_t *)src, (pipe_lds_t *)(stage + r * RS_STRIDE), 16, 0, 0);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            if (valid) {
+                const float *xs = stage + l * RS_STRIDE;
+                const float *qs = qrow_lds + c0;
+#pragma unroll 16
+                for (int j = 0; j < len / 4; ++j) {
+                    const f32x4 xv = *reinterpret_cast<const f32x4 *>(xs + 4 * j);
+                    const f32x4 a = *reinterpret_cast<const f32x4 *>(qs + 4 * j);
+                    sc = __builtin_fmaf(a[0], xv[0], sc);
+                    sc = __builtin_fmaf(a[1], xv[1], sc);
+                    sc = __builtin_fmaf(a[2], xv[2], sc);
+                    sc = __builtin_fmaf(a[3], xv[3], sc);
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the next pieces overwrite the stage
+            __builtin_amdgcn_wave_barrier();
         }
+        const u64 v = valid ? pack_key(sc, prow) : 0ull;
 #pragma unroll
-        for (int j = 0; j < F_NPL; ++j) keys[j] = (j == r) ? v : keys[j];  // r is wave-uniform: register file stays static
+        for (int j = 0; j < F_NPL; ++j) keys[j] = (j == rnd) ? v : keys[j];  // rnd is wave-uniform: register file stays static
     }
     if (n_band > P.k) {
         float tau_new;
@@ -1060,6 +1055,9 @@ int ip_topk_fast(const float *d_x, int64_t n, int64_t row_base, const void *d_in
             hipFuncSetAttribute(reinterpret_cast<const void *>(ip_topk_fast_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)F_LDS_BYTES) != hipSuccess)
             return check_launch("ip_topk_fast attr");
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(rescore_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)rescore_lds_bytes(F_MAX_D)) != hipSuccess)
+            return check_launch("rescore attr");
         attr_done = true;
     }
     const float slack_rel = 1.25f * (9.765625e-4f + 2.1f * d * 5.9604645e-8f);
@@ -1103,9 +1101,8 @@ int ip_topk_fast(const float *d_x, int64_t n, int64_t row_base, const void *d_in
             RescoreParams R;
             R.q32 = P.q32; R.x32 = d_x; R.qnorm = qn; R.hdr = H; R.live2row = P.live2row; R.cand = cand; R.cnt_g = cnt_g; R.thr_g = thr_g;
             R.part = part; R.nq = P.nq; R.d = d; R.k = k; R.S = pl.S; R.slack_rel = slack_rel; R.slack_abs = slack_abs;
-            const size_t lds = (size_t)4 * (d + F_C / 2) * sizeof(float);
             ProfScope ps(PC_RESCORE, st);
-            hipLaunchKernelGGL(rescore_kernel, dim3((unsigned)(P.n_qt * pl.S * FQ / 4)), dim3(256), lds, st, R);
+            hipLaunchKernelGGL(rescore_kernel, dim3((unsigned)(P.n_qt * pl.S * FQ)), dim3(64), rescore_lds_bytes(d), st, R);
         }
         // queries whose buffers overflowed: redone by the exact scan, one by one (<= OVF_CAP) or as a whole chunk
         hipLaunchKernelGGL(gather_overflow_kernel, dim3(OVF_CAP), dim3(256), 0, st, ctl, ovf_list, d_q + (size_t)q0 * d, d, qfb, fb_slot);
