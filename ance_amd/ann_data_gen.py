@@ -9,8 +9,9 @@ What is different is where the work happens:
     (the reference strides records over ranks and round-trips 27 GB through ``.npy`` files,
     utils/util.py:87-146);
   * search runs on every GPU against its resident shard (the reference searches on rank 0's CPU
-    with faiss, :265-303); per-shard top-k lists are all-gathered over RCCL and merged under the
-    canonical order (score desc, row id asc), so ``I`` is independent of the GPU count;
+    with faiss, :265-303); per-shard top-k lists are exchanged by query owner (one RCCL all-to-all),
+    merged under the canonical order (score desc, row id asc) and gathered on rank 0, so ``I`` is
+    independent of the GPU count;
   * row id == record offset (FirstP) or record * chunks + chunk (MaxP).
 
 Launch: one process per GPU, e.g.
@@ -94,19 +95,51 @@ class Dist:
             return t
         pad = torch.zeros((per,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
         pad[:t.shape[0]] = t
+        dev = pad.device
+        if self._host_staged(pad):
+            pad = pad.cpu()
         parts = [torch.empty_like(pad) for _ in range(self.world)]
         self.dist.all_gather(parts, pad)
-        return torch.cat(parts, dim=0)
+        return torch.cat(parts, dim=0).to(dev)
 
-    def all_gather_stack(self, t):
-        """[world, *t.shape] of equal-shaped tensors."""
+    def _host_staged(self, t):
+        """gloo moves host memory only: a device tensor is staged through the host for it (functional multi-rank
+        tests on one GPU; RCCL -- backend "nccl" -- takes device tensors as they are)."""
+        return self.on and t.is_cuda and self.dist.get_backend() == "gloo"
+
+    def all_to_all_blocks(self, t):
+        """``t`` = [world * per, ...]: block j goes to rank j.  Returns [world, per, ...] with [p] = the block rank p
+        sent here (one ``all_to_all_single`` over xGMI)."""
         import torch
         if not self.on or self.world == 1:
             return t.unsqueeze(0)
         t = t.contiguous()
-        parts = [torch.empty_like(t) for _ in range(self.world)]
-        self.dist.all_gather(parts, t)
-        return torch.stack(parts, dim=0)
+        dev = t.device
+        src = t.cpu() if self._host_staged(t) else t
+        out = torch.empty_like(src)
+        self.dist.all_to_all_single(out, src)
+        out = out.to(dev)
+        return out.view((self.world, t.shape[0] // self.world) + tuple(t.shape[1:]))
+
+    def gather_rows_to_root(self, t):
+        """Concatenation of every rank's equal-shaped ``t`` in rank order on rank 0; None elsewhere."""
+        import torch
+        if not self.on or self.world == 1:
+            return t
+        t = t.contiguous()
+        dev = t.device
+        src = t.cpu() if self._host_staged(t) else t
+        parts = [torch.empty_like(src) for _ in range(self.world)] if self.rank == 0 else None
+        self.dist.gather(src, parts, dst=0)
+        return torch.cat(parts, dim=0).to(dev) if self.rank == 0 else None
+
+    def broadcast_object(self, obj):
+        """rank 0's ``obj`` on every rank."""
+        if not self.on or self.world == 1:
+            return obj
+        box = [obj]
+        self.dist.broadcast_object_list(box, src=0)
+        return box[0]
 
 
 # -------------------------------------------------------------------------------------- engine --
@@ -121,6 +154,7 @@ class HipEngine:
         self.torch = torch
         self.device = torch.device(device if device is not None else "cuda")
         self.block_records = block_records
+        self._index = None
 
     def encode_cache(self, model, cache, r0, r1, is_query, chunks=1):
         """Embeddings of records [r0, r1) of a TokenCache -> device fp32 [(r1-r0) * chunks, 768]."""
@@ -151,10 +185,22 @@ class HipEngine:
         return out
 
     def search(self, x, row_base, q, k):
+        """Exact top-k of ``q`` over the resident shard ``x``.  The index (fp16 search image + workspace) of the last
+        shard searched is kept: a refresh searches the same embeddings two or three times (dev, train, trivia --
+        drivers/run_ann_data_gen.py:276,303) and faiss builds its index once too."""
         from .index import FlatIPIndex
-        idx = FlatIPIndex(x.shape[1], device=self.device, row_base=row_base)
-        idx.add(x)
-        return idx.search_device(q.contiguous(), k)
+        # the index keeps ``x`` alive, so a later tensor cannot reuse its address while this entry exists
+        key = (x.data_ptr(), tuple(x.shape), int(row_base), getattr(x, "_version", 0))
+        if self._index is None or self._index[0] != key:
+            self._index = None  # drop the old image before the new one is allocated
+            idx = FlatIPIndex(x.shape[1], device=self.device, row_base=row_base)
+            idx.add(x)
+            self._index = (key, idx)
+        return self._index[1].search_device(q.contiguous(), k)
+
+    def release_index(self):
+        """Frees the cached search image (call when the shard's embeddings are about to be replaced)."""
+        self._index = None
 
     def merge(self, D_parts, I_parts):
         from .index import topk_merge_device
@@ -168,14 +214,29 @@ class HipEngine:
 
 
 def sharded_search(engine, dist, x_local, row_base, q_all, k):
-    """Exact top-k of ``q_all`` over the union of every rank's shard: local scan, all-gather of
-    the per-shard lists, canonical merge (the reference's own precedent: utils/eval_mrr.py:137-183)."""
+    """Exact top-k of ``q_all`` over the union of every rank's shard.  Every rank scans its shard for ALL queries; the
+    per-shard lists are then exchanged by QUERY OWNER -- rank j receives every rank's lists for queries
+    [j per, (j + 1) per) with one all-to-all and merges them under the canonical order (the reference's own
+    shard-search-then-merge: utils/eval_mrr.py:137-183) -- and rank 0 gathers the merged blocks.  Per rank that is
+    nq k 12 bytes received instead of world x as much with an all-gather, and nq / world merges instead of nq.
+    Returns (D, I) on rank 0 and (None, None) elsewhere (only rank 0 post-processes)."""
     D, I = engine.search(x_local, row_base, q_all, k)
     if dist.world == 1:
         return D, I
-    Dp = dist.all_gather_stack(D)
-    Ip = dist.all_gather_stack(I)
-    return engine.merge(Dp, Ip)
+    import torch
+    nq = D.shape[0]
+    per = (nq + dist.world - 1) // dist.world
+    if per * dist.world != nq:  # empty lists for the padding queries
+        Dp = torch.full((per * dist.world, k), torch.finfo(torch.float32).min, dtype=D.dtype, device=D.device)
+        Ip = torch.full((per * dist.world, k), -1, dtype=I.dtype, device=I.device)
+        Dp[:nq] = D
+        Ip[:nq] = I
+        D, I = Dp, Ip
+    Dm, Im = engine.merge(dist.all_to_all_blocks(D), dist.all_to_all_blocks(I))
+    D_all, I_all = dist.gather_rows_to_root(Dm), dist.gather_rows_to_root(Im)
+    if dist.rank != 0:
+        return None, None
+    return D_all[:nq], I_all[:nq]
 
 
 def encode_collection(engine, dist, model, cache, is_query, chunks=1, r_begin=0, r_end=None):
@@ -269,6 +330,8 @@ def generate_new_ann(args, output_num, checkpoint_path, training_query_positive_
         negatives.write_ann_files(args.output_dir, output_num, I.shape[0], q2id, effective_q_id,
                                   training_query_positive_id, neg, dev_ndcg, checkpoint_path)
         result = (dev_ndcg, n_dev_eval)
+    if hasattr(engine, "release_index"):
+        engine.release_index()  # the shard's embeddings die with this refresh
     dist.barrier()
     return result
 
@@ -304,7 +367,10 @@ def ann_data_gen(args, engine=None, dist=None):
     training_positive_id, dev_positive_id = negatives.load_positive_ids(args.data_dir)
 
     while args.end_output_num == -1 or output_num <= args.end_output_num:
-        next_checkpoint, latest_step_num = get_latest_checkpoint(args)
+        # rank 0 looks at the training directory and every rank follows its decision: two ranks scanning on their own
+        # can straddle a checkpoint commit, and then one of them enters the refresh's collectives while the other
+        # sleeps and goes for the barrier
+        next_checkpoint, latest_step_num = dist.broadcast_object(get_latest_checkpoint(args) if dist.rank == 0 else None)
         if args.only_keep_latest_embedding_file:
             latest_step_num = 0
         if next_checkpoint == last_checkpoint:

@@ -129,6 +129,8 @@ def generate_new_ann(args, output_num, checkpoint_path, preloaded_data, latest_s
             json.dump(payload, f)
         os.replace(ndcg_path + ".tmp", ndcg_path)
         result = payload
+    if hasattr(engine, "release_index"):
+        engine.release_index()
     dist.barrier()
     return result
 
@@ -146,7 +148,8 @@ def ann_data_gen(args, engine=None, dist=None, preloaded=None, pool=None):
         if preloaded is None:
             preloaded = load_data(args)
     while args.end_output_num == -1 or output_num <= args.end_output_num:
-        next_checkpoint, latest_step_num = get_latest_checkpoint(args)
+        # rank 0 decides, every rank follows (see ann_data_gen.ann_data_gen)
+        next_checkpoint, latest_step_num = dist.broadcast_object(get_latest_checkpoint(args) if dist.rank == 0 else None)
         if args.only_keep_latest_embedding_file:
             latest_step_num = 0
         if next_checkpoint == last_checkpoint:

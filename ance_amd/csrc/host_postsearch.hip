@@ -81,7 +81,8 @@ struct PyMT {
     }
 };
 
-bool valid_state(const uint32_t *s) { return s != nullptr && s[624] >= 1 && s[624] <= 624; }
+// CPython accepts any index in [0, 624] through random.setstate (0 right after its own regenerate)
+bool valid_state(const uint32_t *s) { return s != nullptr && s[624] <= 624; }
 
 struct SelectJob {
     const int64_t *I;

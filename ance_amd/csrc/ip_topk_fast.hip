@@ -385,6 +385,8 @@ struct FastParams {
     int prune_at;           // first prune of a list at this many rows (<= F_C - FP); later ones when the list has doubled
     int tile_sync;          // keep the 32 workgroups of an XCD group on the same corpus tile step (bounded wait)
     unsigned int tile_wait_ticks;
+    int dbg;                     // STAMPS kernel only, timing experiments (results WRONG): 1 = no insertions after window 4,
+                                 // 2 = no filter at all after window 4, 3 = as 2 and no prune check either
     unsigned long long *stamps;  // measurement: [workgroup][8] accumulated 100 MHz ticks (STAMPS kernel only)
 };
 
@@ -576,6 +578,9 @@ __global__ void __launch_bounds__(F_THREADS, 2) ip_topk_fast_kernel(const FastPa
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int y = 0; y < 4; ++y) {
+            if constexpr (STAMPS) {
+                if (P.dbg >= 2 && win > 4) continue;
+            }
             const int ql = qf + y * 32;
             const bool qv = (q0 + ql) < P.nq;
             const float thr = thr_s[ql];  // -inf until the first prune
@@ -596,6 +601,9 @@ __global__ void __launch_bounds__(F_THREADS, 2) ip_topk_fast_kernel(const FastPa
             if (!ragged) {
                 const float mx = max3_f32(max3_f32(mq[0], mq[1], mq[2]), mq[3], mq[3]);
                 if (__ballot(qv && !(mx < thr)) == 0ull) continue;
+            }
+            if constexpr (STAMPS) {
+                if (P.dbg == 1 && win > 4) continue;
             }
             u64 *cq = cand + (size_t)ql * F_C;
 #pragma unroll
@@ -1088,7 +1096,7 @@ int ip_topk_fast(const float *d_x, int64_t n, int64_t row_base, const void *d_in
         P.grp_ctr = reinterpret_cast<unsigned int *>(ovf_list + OVF_CAP);
         P.prune_at = prune_at > k + 64 ? prune_at : k + 64;
         P.tile_sync = tile_sync; P.tile_wait_ticks = (unsigned)(tile_wait_us > 0 ? tile_wait_us * 100 : 0);
-        P.stamps = stamps;
+        P.stamps = stamps; P.dbg = env_int("ANCE_FAST_DEBUG", 0);
         const int gq = 32 / pl.S;
         const int groups = (P.n_qt + gq - 1) / gq;
         const unsigned blocks = (unsigned)((groups + 7) / 8 * 8) * 32u;

@@ -333,10 +333,12 @@ def main():
             qps = a.query_block * a.steps / dt
             scan = prof["ip_topk_scan"]
             # the category also counts the (device-side conditional, normally no-op) exact fallback launch
-            n_scan = max(scan["count"] // 2, 1) if os.environ.get("ANCE_SEARCH") != "exact" else max(scan["count"], 1)
+            n_scan = max(scan["count"], 1)  # (the device-side conditional redo launches of the fast path are not profiled)
             ach = scan["work"] / (scan["ms"] * 1e-3) / 1e12 if scan["ms"] > 0 else None
-            D, I = res["DI"]
-            ok = bool((D[:, 1:] <= D[:, :-1]).all().item()) and bool((I >= 0).all().item())
+            D, I = res["DI"]  # rank 0 holds the merged lists
+            ok = None
+            if rank == 0:
+                ok = bool((D[:, 1:] <= D[:, :-1]).all().item()) and bool((I >= 0).all().item())
             out["search"] = {"metric": "top%d_queries_per_sec" % a.topk, "value": qps, "unit": "queries/s",
                              "ms_per_step": 1e3 * dt / a.steps, "dtype": "f16 filter + f32 exact re-score (results bit-identical to the f32 scan)", "scaling": "strong (corpus sharded)",
                              "rows_total": a.n_passages, "rows_per_gpu": n_loc, "sorted_and_valid": ok,

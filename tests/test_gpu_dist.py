@@ -1,0 +1,62 @@
+"""N > 1 path on a real device: two ranks share cuda:0 (gloo rendezvous -- RCCL refuses two ranks on one GPU), each
+with the real HipEngine and Dist: contiguous record sharding, per-rank HIP encode, query all-gather, per-shard HIP search
+with row_base, all-to-all by query owner, HIP merge, gather on rank 0, native post-search stage.  The files must be
+byte-identical to the single-rank run of the same job (SURVEY.md 8e invariant: results do not depend on the GPU count).
+Also a three-rank run: a shard count that does not divide the collection sizes."""
+import os
+import random
+import sys
+import types
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _job(rank, world, data, ckpt, out, port):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from ance_amd import ann_data_gen as adg
+    from ance_amd import negatives
+    torch.cuda.set_device(0)
+    if world > 1:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    args = types.SimpleNamespace(data_dir=data, output_dir=out, cache_dir=out, inference=False, topk_training=100,
+                                 negative_sample=8, ann_chunk_factor=1, ann_measure_topk_mrr=False, model_type="rdot_nll",
+                                 max_seq_length=64, max_query_length=32, device=torch.device("cuda", 0), max_tokens=16384)
+    train_pos, dev_pos = negatives.load_positive_ids(data)
+    random.seed(4321)
+    d = adg.Dist()
+    assert d.world == world and d.rank == rank
+    res = adg.generate_new_ann(args, 0, ckpt, train_pos, dev_pos, 100, engine=adg.HipEngine(args.device), dist=d)
+    assert (res is not None) == (rank == 0)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def test_multi_rank_refresh_on_one_gpu(tmp_path):
+    from safetensors.torch import save_file
+    from oracle import encoder_ref, synth
+    data = str(tmp_path / "data")
+    synth.make_msmarco_like(data, n_passages=20000, n_train=1500, n_dev=301, L=64, Lq=32, seed=11, len_median=30)
+    sd = encoder_ref.random_state_dict(seed=5, n_layers=2, ln_jitter=0.1)
+    ckpt = tmp_path / "checkpoint-100"
+    ckpt.mkdir()
+    save_file({k: v.contiguous() for k, v in sd.items()}, str(ckpt / "model.safetensors"))
+    outs = {}
+    for world in (1, 2, 3):
+        out = str(tmp_path / ("w%d" % world))
+        port = 29600 + (os.getpid() + world) % 2000
+        if world == 1:
+            _job(0, 1, data, str(ckpt) + "/", out, port)
+        else:
+            torch.multiprocessing.spawn(_job, args=(world, data, str(ckpt) + "/", out, port), nprocs=world, join=True)
+        outs[world] = {n: open(os.path.join(out, n)).read() for n in ("ann_training_data_0", "ann_ndcg_0")}
+        assert outs[world]["ann_training_data_0"].count("\n") == 1500
+    assert outs[2] == outs[1], "2 ranks"
+    assert outs[3] == outs[1], "3 ranks"

@@ -178,6 +178,20 @@ def test_native_shuffle_continues_cpython_stream():
         assert random.getstate() == after_ref  # the very next draw of a caller is unchanged too
 
 
+def test_native_shuffle_accepts_state_index_zero():
+    """CPython's setstate takes any index in [0, 624]; index 0 is what its own regenerate leaves."""
+    random.seed(77)
+    ver, internal, gauss = random.getstate()
+    st0 = (ver, tuple(internal[:624]) + (0,), gauss)
+    random.setstate(st0)
+    ref = list(range(500))
+    random.shuffle(ref)
+    after_ref = random.getstate()
+    random.setstate(st0)
+    got = negatives.py_shuffled_range(500)
+    assert got.tolist() == ref and random.getstate() == after_ref
+
+
 def _random_case(rng, nq, k, n_rows, chunks, dup_q=False, with_pad=False, inactive=False):
     p2id = (np.arange(n_rows) // chunks).astype(np.int64)
     q2id = np.arange(1000, 1000 + nq, dtype=np.int64)
