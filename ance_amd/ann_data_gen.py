@@ -269,10 +269,33 @@ def gather_queries(dist, emb_local, n_total):
 # ----------------------------------------------------------------------------------- the job --
 
 
+class _Phases:
+    """Wall time per phase of a refresh (``args.timings``: a dict to fill, or absent).  A phase ends with a device
+    synchronisation so that its kernels are charged to it -- only when somebody asked for timings."""
+
+    def __init__(self, sink):
+        self.sink = sink
+        self.t = time.perf_counter()
+
+    def mark(self, name):
+        if self.sink is None:
+            return
+        try:
+            import torch
+            if torch.cuda.is_available():
+                torch.cuda.synchronize()
+        except Exception:
+            pass
+        now = time.perf_counter()
+        self.sink[name] = self.sink.get(name, 0.0) + (now - self.t)
+        self.t = now
+
+
 def generate_new_ann(args, output_num, checkpoint_path, training_query_positive_id, dev_query_positive_id,
                      latest_step_num, engine=None, model=None, dist=None):
     """One refresh (drivers/run_ann_data_gen.py:231-336).  Returns (dev_ndcg, n_dev_queries) on rank 0."""
     dist = dist or Dist()
+    ph = _Phases(getattr(args, "timings", None))
     if engine is None:
         engine = HipEngine(getattr(args, "device", None))
     if model is None:
@@ -280,15 +303,18 @@ def generate_new_ann(args, output_num, checkpoint_path, training_query_positive_
         model = load_model(args.model_type, checkpoint_path, max_seq_length=args.max_seq_length,
                            max_tokens=getattr(args, "max_tokens", 65536), device=getattr(args, "device", None))
     chunks = getattr(model, "chunks", 1)
+    ph.mark("load_model")
 
     logger.info("***** inference of dev query *****")
     dev_cache = TokenCache(os.path.join(args.data_dir, "dev-query"))
     dev_local, _, n_dev = encode_collection(engine, dist, model, dev_cache, True)
+    ph.mark("encode_dev_queries")
 
     logger.info("***** inference of passages *****")
     p_cache = TokenCache(os.path.join(args.data_dir, "passages"))
     p_local, p_row0, n_rows = encode_collection(engine, dist, model, p_cache, False, chunks)
     logger.info("***** Done passage inference *****")
+    ph.mark("encode_passages")
 
     if args.inference:
         _dump_inference(args, engine, dist, latest_step_num, dev_local, p_local, p_row0, chunks, None, 0)
@@ -302,13 +328,17 @@ def generate_new_ann(args, output_num, checkpoint_path, training_query_positive_
     # only the chunk that will be searched is encoded: rows are independent, the result is the same
     q_local, _, n_q = encode_collection(engine, dist, model, q_cache, True, 1, q_start, q_end)
     logger.info("Chunked %d query from %d", n_q, nq_all)
+    ph.mark("encode_train_queries")
 
     dev_all = gather_queries(dist, dev_local, n_dev)
     q_all = gather_queries(dist, q_local, n_q)
+    ph.mark("gather_queries")
 
     _, dev_I = sharded_search(engine, dist, p_local, p_row0, dev_all, 100)
+    ph.mark("search_dev")
     _, I = sharded_search(engine, dist, p_local, p_row0, q_all, args.topk_training)
     logger.info("***** Done ANN Index *****")
+    ph.mark("search_train")
 
     result = None
     if dist.rank == 0:
@@ -332,6 +362,7 @@ def generate_new_ann(args, output_num, checkpoint_path, training_query_positive_
         result = (dev_ndcg, n_dev_eval)
     if hasattr(engine, "release_index"):
         engine.release_index()  # the shard's embeddings die with this refresh
+    ph.mark("host_stage")
     dist.barrier()
     return result
 

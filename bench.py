@@ -54,7 +54,114 @@ def parse():
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="time budget per CPU-baseline leg")
     p.add_argument("--skip-search", action="store_true")
     p.add_argument("--skip-encode", action="store_true")
+    p.add_argument("--full", action="store_true",
+                   help="measure ONE real refresh instead of the step benchmark: write the tokenised caches of "
+                        "--n-passages passages / --full-queries train queries to --full-dir, then run "
+                        "ance_amd.ann_data_gen.generate_new_ann on them (stream from disk, encode, search, host stage, "
+                        "files) and print the wall time per phase")
+    p.add_argument("--full-dir", type=str, default="/tmp/ance_full")
+    p.add_argument("--full-queries", type=int, default=N_TRAIN_QUERIES)
+    p.add_argument("--full-dev-queries", type=int, default=6980)
+    p.add_argument("--negative-sample", type=int, default=20)
     return p.parse_args()
+
+
+def write_synthetic_cache(path, n, L, median, sigma, lo, seed, block=1 << 20):
+    """Reference cache format (utils/util.py:257-307 reads it; ance_amd.cache.TokenCache maps it), written in
+    blocks so that the 4.56 GB passage file never sits in host memory.  Returns (seconds, mean length)."""
+    t0 = time.perf_counter()
+    rng = np.random.default_rng(seed)
+    tot = 0
+    with open(path, "wb") as f:
+        for b0 in range(0, n, block):
+            m = min(block, n - b0)
+            lens = np.clip(np.rint(rng.lognormal(np.log(median), sigma, size=m)), lo, L).astype(np.int32)
+            ids = rng.integers(3, 50265, size=(m, L), dtype=np.int32)
+            ids[:, 0] = 0
+            ids[np.arange(m), lens - 1] = 2
+            ids[np.arange(L)[None, :] >= lens[:, None]] = 1
+            rec = np.empty((m, 1 + L), dtype=np.int32)
+            rec[:, 0] = lens.astype(">u4").view(np.int32)
+            rec[:, 1:] = ids
+            f.write(rec.tobytes())
+            tot += int(lens.sum())
+    with open(path + "_meta", "w") as f:
+        json.dump({"type": "int32", "total_number": int(n), "embedding_size": int(L)}, f)
+    return time.perf_counter() - t0, tot / max(n, 1)
+
+
+def full_refresh(a):
+    """the path the reference actually runs (drivers/run_ann_data_gen.py:231-336 over
+    utils/util.py:257-329), measured end to end on this box instead of extrapolated from one resident block."""
+    import types
+    import torch
+    from safetensors.torch import save_file
+    from ance_amd import ann_data_gen as adg
+    from ance_amd import negatives
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count()
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        torch.distributed.init_process_group(backend=os.environ.get("ANCE_BENCH_BACKEND", "nccl"))
+    d = a.full_dir
+    data, ckpt, outd = os.path.join(d, "data"), os.path.join(d, "checkpoint-1"), os.path.join(d, "out")
+    prep = {}
+    if rank == 0:
+        for sub in (data, ckpt, outd):
+            os.makedirs(sub, exist_ok=True)
+        prep["write_passages_s"], mean_p = write_synthetic_cache(os.path.join(data, "passages"), a.n_passages, a.seq_len, 70.0,
+                                                                 0.45, 8, 1)
+        prep["write_train_queries_s"], mean_q = write_synthetic_cache(os.path.join(data, "train-query"), a.full_queries, 64,
+                                                                      9.0, 0.35, 4, 2)
+        prep["write_dev_queries_s"], _ = write_synthetic_cache(os.path.join(data, "dev-query"), a.full_dev_queries, 64, 9.0,
+                                                               0.35, 4, 3)
+        prep["mean_passage_len"], prep["mean_query_len"] = mean_p, mean_q
+        rng = np.random.default_rng(4)
+        with open(os.path.join(data, "train-qrel.tsv"), "w") as f:
+            pos = rng.integers(0, a.n_passages, size=a.full_queries)
+            f.write("".join("%d\t%d\t1\n" % (q, p) for q, p in enumerate(pos.tolist())))
+        with open(os.path.join(data, "dev-qrel.tsv"), "w") as f:
+            pos = rng.integers(0, a.n_passages, size=a.full_dev_queries)
+            f.write("".join("%d\t%d\t1\n" % (q, p) for q, p in enumerate(pos.tolist())))
+        save_file({k: v.contiguous() for k, v in random_init_roberta_base(torch, a.layers, seed=0).items()},
+                  os.path.join(ckpt, "model.safetensors"))
+    dist = adg.Dist()
+    dist.barrier()
+    timings = {}
+    args = types.SimpleNamespace(data_dir=data, output_dir=outd, cache_dir=outd, inference=False, topk_training=a.topk,
+                                 negative_sample=a.negative_sample, ann_chunk_factor=1, ann_measure_topk_mrr=False,
+                                 model_type="rdot_nll", max_seq_length=a.seq_len, max_query_length=64, device=dev,
+                                 max_tokens=a.max_tokens, timings=timings)
+    import random
+    random.seed(0)
+    t0 = time.perf_counter()
+    train_pos, dev_pos = negatives.load_positive_ids(data)
+    t_qrels = time.perf_counter() - t0
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    res = adg.generate_new_ann(args, 0, ckpt + "/", train_pos, dev_pos, 1, dist=dist)
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    if rank == 0:
+        lines = sum(1 for _ in open(os.path.join(outd, "ann_training_data_0")))
+        enc_s = timings.get("encode_passages", 0.0)
+        out = {"metric": "full_refresh_seconds", "value": wall, "unit": "s", "n_gpus": world, "higher_is_better": False,
+               "dtype": "f16", "data": "synthetic",
+               "config": {"workload": "one ANN refresh: %d passages (seq_len %d, streamed from %s) + %d train queries "
+                                      "(ann_chunk_factor 1) + %d dev queries, top-%d, %d negatives, roberta-base rdot_nll "
+                                      "random init" % (a.n_passages, a.seq_len, d, a.full_queries, a.full_dev_queries, a.topk,
+                                                       a.negative_sample)},
+               "phases_s": {k: round(v, 3) for k, v in timings.items()}, "load_qrels_s": round(t_qrels, 3),
+               "prepare_s": {k: round(v, 3) for k, v in prep.items()},
+               "passages_per_sec_measured": a.n_passages / enc_s if enc_s > 0 else None,
+               "train_queries_per_sec_measured": a.full_queries / timings["search_train"] if timings.get("search_train") else None,
+               "lines_written": lines, "dev_ndcg": res[0] if res else None}
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
 
 
 def synthetic_records(rng, n, L):
@@ -203,6 +310,8 @@ def cpu_search_baseline(n_rows_total, k, seconds):
 
 def main():
     a = parse()
+    if a.full:
+        return full_refresh(a)
     import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

@@ -57,7 +57,7 @@ def _additive_mask(mask):
     # fp32 whenever at least one key is kept, and give the same (uniform / identical-key) result
     # for an all-masked row of identical pad tokens.
     keep = mask.to(torch.bool)
-    add = torch.zeros(mask.shape, dtype=torch.float32)
+    add = torch.zeros(mask.shape, dtype=torch.float32, device=mask.device)  # (device: the GPU-resident reference of tests/test_gpu_retrieval.py)
     add = add.masked_fill(~keep, torch.finfo(torch.float32).min)
     return add[:, None, None, :]
 

@@ -1,7 +1,8 @@
 """Parity of the HIP dual encoder (through the C ABI) with the fp32 oracle and with golden vectors
 of the real reference.  Tolerance (stated): fp16 MFMA operands with fp32 accumulation and an fp32
-residual stream against the reference's fp32 arithmetic -> max |delta| <= 1e-2 on unit-variance
-embeddings and cosine >= 0.9999 per row (measured headroom ~4x).  Needs an MI355X."""
+residual stream against the reference's fp32 arithmetic -> max |delta| <= 5e-3 on unit-variance
+embeddings and cosine >= 0.99999 per row (measured: 3.0e-3 / 0.9999997 at 12 layers; what that
+tolerance means for retrieval is measured by tests/test_gpu_retrieval.py).  Needs an MI355X."""
 import json
 import os
 
@@ -11,8 +12,8 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-ABS_TOL = 1e-2
-COS_TOL = 0.9999
+ABS_TOL = 5e-3
+COS_TOL = 0.99999
 OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
 
 
