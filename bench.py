@@ -12,8 +12,9 @@ A "step" is one pass of the hot path over one batch of synthetic input, timed pe
                rdot_nll, records already resident in HBM) -> value = passages/s over all ranks;
   search leg : --query-block queries, exact IP top-200 against the 8,841,823 x 768 fp32 corpus that
                is resident in HBM, sharded over the ranks (contiguous row blocks), per-shard lists
-               all-gathered over RCCL and merged -> queries/s (the refresh searches 100k-503k queries,
-               in launch chunks of 32,768: that is the step).
+               exchanged by query owner over RCCL (all-to-all), merged, gathered on rank 0 -> queries/s
+               (the refresh searches 100k-503k queries, in launch chunks of 32,768: that is the step).
+    python bench.py --full   measures ONE real refresh end to end instead (caches on disk -> files), per phase.
 Both legs: W untimed warm-up steps, then exactly K steps between barrier + synchronize on both
 sides, MAX over ranks.  Rank 0 prints ONE JSON line.  `roofline` comes from HIP events the library
 records around every kernel launch on the launch stream during the timed steps; `cpu_baseline` is
@@ -341,7 +342,7 @@ def main():
            "config": {"workload": "MS MARCO passage %d x 768-d, roberta-base rdot_nll FirstP seq_len=%d, encode + "
                                   "brute-force IP top-%d (BASELINE configs[1])" % (a.n_passages, a.seq_len, a.topk),
                       "encode_block_per_gpu": a.encode_block, "query_block": a.query_block, "layers": a.layers,
-                      "parallelism": "dp%d (corpus rows sharded, top-k all-gather + merge)" % world}}
+                      "parallelism": "dp%d (corpus rows sharded, top-k all-to-all by query owner + merge)" % world}}
 
     # ------------------------------------------------------------------------------ encode leg --
     if not a.skip_encode:
@@ -440,26 +441,48 @@ def main():
             prof = _lib.profile_read()
             _lib.profile_enable(False)
             qps = a.query_block * a.steps / dt
-            scan = prof["ip_topk_scan"]
-            # the category also counts the (device-side conditional, normally no-op) exact fallback launch
+            scan, resc, fin = prof["ip_topk_scan"], prof["ip_topk_rescore"], prof["topk_finalize"]
             n_scan = max(scan["count"], 1)  # (the device-side conditional redo launches of the fast path are not profiled)
             ach = scan["work"] / (scan["ms"] * 1e-3) / 1e12 if scan["ms"] > 0 else None
             D, I = res["DI"]  # rank 0 holds the merged lists
             ok = None
             if rank == 0:
                 ok = bool((D[:, 1:] <= D[:, :-1]).all().item()) and bool((I >= 0).all().item())
+            # the search image (fp16 rows, duplicate classes) is built once per refresh, not per step: time it alone
+            torch.cuda.synchronize()
+            t_b = time.perf_counter()
+            from ance_amd.index import FlatIPIndex
+            probe = FlatIPIndex(768, device=dev)
+            probe.add(x)
+            probe._search_image(_lib.lib(), x)
+            torch.cuda.synchronize()
+            build_ms = 1e3 * (time.perf_counter() - t_b)
+            del probe
+            traffic = pmc_traffic("search", "ip_topk_fast")
+            # what the counters say limits the filter kernel (profiles/pmc_traffic.json, scripts/gpu_pmc.sh): the MFMA pipe
+            # when it is busy most of the cycles, else the memory side feeding it
+            bound = "mfma"
+            if traffic and traffic.get("cycles") and (traffic["cycles"].get("mfma_busy_frac") or 1.0) < 0.5:
+                bound = "mfma (pipe busy %.0f %% of the cycles at %.2f GHz: the rest is LDS-DMA issue, barriers and the filter between " \
+                        "corpus tiles; L2-fill traffic %.2f TB per launch)" % (100 * traffic["cycles"]["mfma_busy_frac"],
+                                                                                traffic["cycles"]["clock_ghz"], traffic["fetch_bytes_x2"] / 1e12)
             out["search"] = {"metric": "top%d_queries_per_sec" % a.topk, "value": qps, "unit": "queries/s",
                              "ms_per_step": 1e3 * dt / a.steps, "dtype": "f16 filter + f32 exact re-score (results bit-identical to the f32 scan)", "scaling": "strong (corpus sharded)",
                              "rows_total": a.n_passages, "rows_per_gpu": n_loc, "sorted_and_valid": ok,
                              "full_train_queries_seconds_est": N_TRAIN_QUERIES / qps,
-                             "roofline": {"bound": "mfma",
-                                          "kernel": "ip_topk_fast_kernel (fp16 MFMA 32x32x16 filter + exact fp32 fmaf-chain "
-                                                    "re-scoring; algorithmic FLOPs = 2 nq n d)",
+                             "search_image_build_ms": build_ms,
+                             "roofline": {"bound": bound,
+                                          "kernel": "ip_topk_fast_kernel (fp16 MFMA 32x32x16 filter; algorithmic FLOPs = 2 nq n d = "
+                                                    "1,536 per query-row pair)",
                                           "achieved": ach, "peak": PEAK_F16_TF, "unit": "TFLOP/s",
-                                          "frac": (ach / PEAK_F16_TF) if ach else None, "traffic": pmc_traffic("search", "ip_topk_fast"),
+                                          "frac": (ach / PEAK_F16_TF) if ach else None, "traffic": traffic,
                                           "ms_per_launch": scan["ms"] / n_scan,
-                                          "finalize_ms_per_launch": prof["topk_finalize"]["ms"] / max(prof["topk_finalize"]["count"], 1),
-                                          "hbm_read_gbs_min": ((n_loc * 768 * 4.0) / (scan["ms"] / max(scan["count"], 1) * 1e-3) / 1e9)
+                                          "rescore_ms_per_launch": resc["ms"] / max(resc["count"], 1),
+                                          "rescore_kernel": "rescore_kernel (exact fp32 fmaf chains of the ~k + 66 band rows per list; "
+                                                            "HBM-bound gather of 3 KB rows)",
+                                          "finalize_ms_per_launch": fin["ms"] / max(fin["count"], 1),
+                                          "whole_step_tflops": 2.0 * a.query_block * a.n_passages * 768 * a.steps / dt / 1e12,
+                                          "hbm_read_gbs_min": ((n_loc * 768 * 2.0) / (scan["ms"] / n_scan * 1e-3) / 1e9)
                                           if scan["ms"] > 0 else None}}
             del x, q
         except Exception as e:
@@ -476,6 +499,15 @@ def main():
                 out["search"]["cpu_baseline"] = cpu_search_baseline(a.n_passages, a.topk, a.cpu_seconds)
         except Exception as e:
             errors["cpu_baseline"] = repr(e)
+    try:  # measured by tests/test_gpu_retrieval.py on an MI355X (fp16-operand encoder vs the fp32 reference arithmetic)
+        with open(os.path.join(ROOT, "profiles", "r02_retrieval_agreement.json")) as f:
+            ra = json.load(f)
+        out["retrieval_agreement"] = {k_: ra[k_] for k_ in ("n_passages", "n_queries", "layers", "k", "max_abs_passage",
+                                                             "recall_at_200", "identical_top1", "first_20_negatives_overlap",
+                                                             "identical_first_20_negatives")}
+        out["retrieval_agreement"]["source"] = "profiles/r02_retrieval_agreement.json (tests/test_gpu_retrieval.py)"
+    except Exception:
+        pass
     if errors:
         out["errors"] = errors
     if dist_on:

@@ -1,24 +1,29 @@
 #!/bin/bash
-# rocprofv3 on the torch-free ABI probe: kernel-trace stats + PMC (HBM bytes) in separate runs.
+# rocprofv3 on the bench legs themselves (distinct random rows -- the tiled corpus of tools/abi_probe is one big duplicate
+# class and no longer representative): kernel-trace stats, then one --pmc pass per counter set (never combined with
+# other trace domains).  The encode leg is traced single-stream (ANCE_ENCODER_STREAMS=1) so that a kernel's duration is
+# its own.  Results: gpurun_out/pmc/**, summary -> gpurun_out/pmc/pmc_traffic.json (copy to profiles/).
 set -u
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out/pmc
 export TMPDIR=/tmp
-export LD_LIBRARY_PATH=/opt/rocm/lib:${LD_LIBRARY_PATH:-}
-S="tools/abi_probe search ${PMC_N:-8841823} ${PMC_NQ:-32768} 200 2"
-E="tools/abi_probe encode ${PMC_NP:-16384} 128 12 2 65536"
-echo "== plain runs"; timeout 300 $S; timeout 300 $E
-for what in search encode; do
+S="python bench.py --skip-encode --no-cpu-baseline --steps ${PMC_STEPS:-2} --warmup 1"
+E="python bench.py --skip-search --no-cpu-baseline --steps ${PMC_STEPS:-2} --warmup 1"
+for what in ${PMC_LEGS:-search encode}; do
   cmd="$S"; [ $what = encode ] && cmd="$E"
+  [ $what = encode ] && export ANCE_ENCODER_STREAMS=1
   echo "== kernel-trace $what"
-  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/pmc/kt_$what -o kt -- $cmd > gpurun_out/pmc/kt_$what.log 2>&1; echo "rc=$?"
+  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/pmc/kt_$what -o kt -- $cmd > gpurun_out/pmc/kt_$what.log 2>&1; echo "rc=$?"
   echo "== pmc cycles $what (GRBM_GUI_ACTIVE = shader clocks of the dispatch: clock-independent cost, and the clock itself)"
-  timeout 600 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES --kernel-trace --output-format csv -d gpurun_out/pmc/CYCLES_$what -o pmc -- $cmd > gpurun_out/pmc/CYCLES_$what.log 2>&1; echo "rc=$?"
+  timeout 900 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES --kernel-trace --output-format csv -d gpurun_out/pmc/CYCLES_$what -o pmc -- $cmd > gpurun_out/pmc/CYCLES_$what.log 2>&1; echo "rc=$?"
+  echo "== pmc L2 hit/miss $what"
+  timeout 900 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d gpurun_out/pmc/L2_$what -o pmc -- $cmd > gpurun_out/pmc/L2_$what.log 2>&1; echo "rc=$?"
   for c in FETCH_SIZE WRITE_SIZE; do
     echo "== pmc $c $what"
-    timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmc/${c}_$what -o pmc -- $cmd > gpurun_out/pmc/${c}_$what.log 2>&1; echo "rc=$?"
-    tail -3 gpurun_out/pmc/${c}_$what.log | cut -c1-200
+    timeout 900 rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmc/${c}_$what -o pmc -- $cmd > gpurun_out/pmc/${c}_$what.log 2>&1; echo "rc=$?"
+    tail -2 gpurun_out/pmc/${c}_$what.log | cut -c1-200
   done
+  unset ANCE_ENCODER_STREAMS
 done
-find gpurun_out/pmc -name "*.csv" | head -30
-python scripts/summarize_pmc.py gpurun_out/pmc gpurun_out/pmc/pmc_traffic.json 2>&1 | head -70
+find gpurun_out/pmc -name "*kernel_trace.csv" -size +8M -delete
+python scripts/summarize_pmc.py gpurun_out/pmc gpurun_out/pmc/pmc_traffic.json 2>&1 | tail -120

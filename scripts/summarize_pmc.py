@@ -72,18 +72,44 @@ if len(sys.argv) > 2:
         return {"cycles_per_launch": g, "mfma_busy_frac": (sum(busy) / len(busy) / g) if busy else None,
                 "clock_ghz": g / t, "ns_per_launch_under_pmc": t}
 
+    def l2_hit(leg, needle):
+        hit = miss = 0.0
+        for f in glob.glob(os.path.join(root, "L2_%s" % leg, "**", "*counter_collection.csv"), recursive=True):
+            with open(f) as fh:
+                for row in csv.DictReader(fh):
+                    if needle not in row.get("Kernel_Name", ""):
+                        continue
+                    if row.get("Counter_Name") == "TCC_HIT_sum":
+                        hit += float(row["Counter_Value"])
+                    elif row.get("Counter_Name") == "TCC_MISS_sum":
+                        miss += float(row["Counter_Value"])
+        return hit / (hit + miss) if hit + miss > 0 else None
+
+    def trace_avg_ns(leg, needle):
+        """average dispatch duration in the plain kernel-trace run (no counters)"""
+        dur = []
+        for f in glob.glob(os.path.join(root, "kt_%s" % leg, "**", "*kernel_trace.csv"), recursive=True):
+            with open(f) as fh:
+                for row in csv.DictReader(fh):
+                    if needle in row.get("Kernel_Name", ""):
+                        dur.append(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
+        return (sum(dur) / len(dur), len(dur)) if dur else (None, 0)
+
     out = {}
     for leg, cat, needle in (("encode", "gemm_ffn1", "gemm256_f16_kernel<1"), ("encode", "gemm_qk", "gemm256_f16_kernel<0"),
                              ("encode", "gemm_res32", "gemm256_f16_kernel<2"), ("encode", "gemm_vt", "gemm256_f16_kernel<3"),
                              ("encode", "layernorm", "ln_kernel"), ("encode", "attention", "attention_kernel"),
-                             ("search", "ip_topk_fast", "ip_topk_fast_kernel"), ("search", "ip_topk_scan", "ip_topk_scan_kernel")):
+                             ("search", "ip_topk_fast", "ip_topk_fast_kernel"), ("search", "ip_topk_rescore", "rescore_kernel"),
+                             ("search", "ip_topk_scan", "ip_topk_scan_kernel")):
         fe, wr = per_dispatch(leg, "FETCH_SIZE", needle), per_dispatch(leg, "WRITE_SIZE", needle)
         if fe is None or wr is None:
             continue
-        out.setdefault(leg, {})[cat] = {"cycles": cycles(leg, needle),
+        avg_ns, n_disp = trace_avg_ns(leg, needle)
+        out.setdefault(leg, {})[cat] = {"cycles": cycles(leg, needle), "l2_hit_rate": l2_hit(leg, needle),
+                                        "kernel_trace_avg_ns": avg_ns, "kernel_trace_dispatches": n_disp,
                                         "hbm_bytes_per_launch": 2.0 * fe + wr, "fetch_bytes_x2": 2.0 * fe, "write_bytes": wr,
-                                        "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on tools/abi_probe, same "
-                                                "workload as bench.py; FETCH_SIZE doubled per MI355X_MICROARCH.md (wide reads on gfx950)"}
+                                        "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / TCC_HIT,MISS / cycles (separate passes) on the bench.py leg "
+                                                "itself (scripts/gpu_pmc.sh); FETCH_SIZE doubled per MI355X_MICROARCH.md (wide reads on gfx950)"}
     with open(sys.argv[2], "w") as f:
         json.dump(out, f, indent=1)
     print(json.dumps(out, indent=1))
