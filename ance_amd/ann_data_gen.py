@@ -288,6 +288,7 @@ class _Phases:
             pass
         now = time.perf_counter()
         self.sink[name] = self.sink.get(name, 0.0) + (now - self.t)
+        logger.info("phase %s: %.2f s", name, now - self.t)
         self.t = now
 
 

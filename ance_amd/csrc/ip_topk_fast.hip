@@ -30,11 +30,18 @@
 //   and redone by the exact fp32 scan -- only those queries; above 1,024 such queries per launch chunk the
 //   whole chunk is redone.  Both are device-side conditionals, no host synchronisation.
 //
-// Error bound, B = sum_k |q_k||x_k| <= ||q|| ||x||, normal-range fp16 (|v| >= 2^-14):
-//   rounding q and x to fp16:  |q.x - qh.xh| <= (2^-11 + 2^-11 + 2^-22) B
-//   fp32 accumulation inside / between MFMAs: <= 1.1 d 2^-24 B ; the exact chain itself: <= d 2^-24 B
-//   fp16 subnormal inputs add at most 2^-25 per element: <= 2^-25 sqrt(d) (||q|| + ||x||)
-// eps = 1.25 * [ (2^-10 + 2.1 d 2^-24) ||q|| max||x||  +  2^-24 sqrt(d) (||q|| + max||x||) ].
+// Error bound.  The image holds xh = fp16(x') with x' = fl32(x - mu), mu = the shard's mean row: q . x = q . (x - mu) + q . mu,
+// and the second term is the same for every row of a query, so ranking by q . x' is ranking by q . x -- but |x'| is what the
+// fp16 rounding error scales with.  Embeddings of one encoder share a large common component (random-init roberta-base:
+// cosine 0.99 between any two passages, scores 737 +- 1.7): without the centring 2 eps is wider than the whole score
+// distribution and every query overflows.  With C the canonical fp32 chain score of (q, x), s~ the filter's score:
+//   rounding q and x' to fp16, normal range:   |q . x' - qh . xh| <= (2^-11 + 2^-11 + 2^-22) |q| |x'|
+//   fp32 accumulation inside / between MFMAs:  <= 1.1 d 2^-24 |q| |x'|
+//   x' = fl32(x - mu):                         <= 2^-24 |q| |x'|        (2^-23 budgeted)
+//   fp16 subnormal inputs, 2^-25 per element:  <= 2^-25 sqrt(d) (|q| + |x'|)
+//   the chain itself, C vs q . x:              <= d 2^-24 |q| |x|       (the un-centred norm)
+// |s~ - (C - q . mu)| <= eps = 1.25 * [ (2^-10 + 1.1 d 2^-24 + 2^-23) |q| max|x'| + 2^-24 sqrt(d) (|q| + max|x'|) + d 2^-24 |q| max|x| ]
+// (tests/test_eps_bound.py attacks it on the CPU).
 #include "common.h"
 #include "topk_common.h"
 #include "pipe256.h"
@@ -49,7 +56,7 @@ constexpr int F_STAGE_HALVES = 2 * F_OPER_HALVES;
 constexpr int F_THREADS = 512;
 constexpr int F_NPL = 32;
 constexpr int F_C = F_NPL * 64;  // 2048 buffered rows per (block, query); a tile can add 256
-constexpr size_t F_LDS_BYTES = (size_t)2 * F_STAGE_HALVES * sizeof(_Float16) + 4 * FQ * 4 + 16;
+constexpr size_t F_LDS_BYTES = (size_t)2 * F_STAGE_HALVES * sizeof(_Float16) + 3 * FQ * 4 + 16;
 constexpr int F_MAX_D = 2048;    // block-end re-scoring keeps 8 fp32 query rows + 8 position lists in the stage area
 constexpr int F_MAX_K = 1024;
 constexpr int OVF_CAP = 1024;    // overflowing queries per launch chunk that are redone one by one
@@ -60,19 +67,23 @@ constexpr int IDX_SAMPLES = 2048;
 constexpr int IDX_MIN_CLASS = 8;  // a duplicate class is collapsed when >= 8 of the 2,048 sampled rows fall in it
 
 struct IndexLayout {
-    size_t x2_off, live_off, mem_off, cls_off, blk_off, samp_off, total;
+    size_t mu_off, x2_off, live_off, mem_off, cls_off, blk_off, samp_off, part_off, total;
     int64_t nb;
+    int n_part;  // row ranges of the column-sum pass
 };
 IndexLayout index_layout(int64_t n, int d) {
     IndexLayout L;
     L.nb = (n + IDX_BLOCK_ROWS - 1) / IDX_BLOCK_ROWS;
     size_t o = 256;
+    L.mu_off = o; o += align_up((size_t)d * sizeof(float), 256);
     L.x2_off = o; o += align_up((size_t)n * d * sizeof(_Float16), 256);
     L.live_off = o; o += align_up((size_t)n * 4, 256);
     L.mem_off = o; o += (size_t)DEDUP_MAXC * DEDUP_MEMCAP * 4;
     L.cls_off = o; o += align_up((size_t)n + 4, 256);
     L.blk_off = o; o += align_up((size_t)(1 + DEDUP_MAXC) * L.nb * 4, 256);
     L.samp_off = o; o += (size_t)IDX_SAMPLES * sizeof(u64);
+    L.n_part = (int)(L.nb < 1024 ? L.nb : 1024);
+    L.part_off = o; o += align_up((size_t)L.n_part * d * sizeof(float), 256);
     L.total = o;
     return L;
 }
@@ -81,6 +92,25 @@ __device__ __forceinline__ u64 mix64(u64 z) {
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
     return z ^ (z >> 31);
+}
+
+// mean row of the shard, pass 1: block b sums the rows b, b + gridDim.x, ... per column (fp32 partials; the mean only has to be a
+// fixed vector near the centre of the rows -- its own accuracy never enters the error bound)
+__global__ void __launch_bounds__(256) idx_colsum_kernel(const float *x, int64_t n, int d, float *part) {
+    for (int c4 = threadIdx.x; c4 * 4 < d; c4 += 256) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int64_t r = blockIdx.x; r < n; r += gridDim.x) acc += *reinterpret_cast<const f32x4 *>(x + (size_t)r * d + c4 * 4);
+        *reinterpret_cast<f32x4 *>(part + (size_t)blockIdx.x * d + c4 * 4) = acc;
+    }
+}
+// pass 2: mu[c] = sum of the partials / n (double), or 0 when centring is off or a partial is not finite
+__global__ void __launch_bounds__(256) idx_mean_kernel(const float *part, int n_part, int64_t n, int d, int center, float *mu) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= d) return;
+    double s = 0.0;
+    for (int p = 0; p < n_part; ++p) s += (double)part[(size_t)p * d + c];
+    const float m = (float)(s / (double)n);
+    mu[c] = (center && m == m && fabsf(m) < 3.0e38f) ? m : 0.0f;
 }
 
 // one wave per sampled row: position-mixed 64-bit hash of the row's bits; low 11 bits carry the sample index
@@ -123,7 +153,6 @@ __global__ void __launch_bounds__(256) idx_find_classes_kernel(const u64 *samp, 
     if (threadIdx.x == 0) {
         H->n_classes = ncls < DEDUP_MAXC ? ncls : DEDUP_MAXC;
         H->n_live = (uint32_t)n;
-        H->xmax_bits = 0;
     }
 }
 
@@ -243,11 +272,11 @@ __global__ void __launch_bounds__(1024) idx_scan_kernel(int64_t nb, DedupHeader 
 // (image position of a kept row, ordinal of a duplicate inside its class); phase B rounds the kept rows to fp16 at
 // their image position (one wave per row) and folds their norms into the shard maximum.
 __global__ void __launch_bounds__(256) idx_compact_round_kernel(const float *x, int64_t n, int d, int64_t nb, DedupHeader *H,
-                                                                const uint8_t *cls, const uint32_t *blk, _Float16 *x2,
-                                                                uint32_t *live2row, uint32_t *members) {
+                                                                const uint8_t *cls, const uint32_t *blk, const float *mu,
+                                                                _Float16 *x2, uint32_t *live2row, uint32_t *members) {
     __shared__ uint32_t pos_s[IDX_BLOCK_ROWS];  // image row of the block's rows, 0xFFFFFFFF for collapsed duplicates
     __shared__ u64 wtot[4];
-    __shared__ float wmax[4];
+    __shared__ float wmax[4], wmaxo[4];
     const int tid = threadIdx.x, l = tid & 63, w = tid >> 6;
     const int64_t r0 = (int64_t)blockIdx.x * IDX_BLOCK_ROWS;
     const int nc = H->n_classes;
@@ -297,35 +326,46 @@ __global__ void __launch_bounds__(256) idx_compact_round_kernel(const float *x, 
         }
     }
     __syncthreads();
-    float mymax = 0.0f;
+    float mymax = 0.0f, mymaxo = 0.0f;
     for (int j = w; j < IDX_BLOCK_ROWS; j += 4) {
         const uint32_t at = pos_s[j];
         if (at == 0xFFFFFFFFu) continue;  // wave-uniform
         const float *s = x + (size_t)(r0 + j) * d;
         _Float16 *hi = x2 + (size_t)at * d;
-        float q = 0.f;
+        float q = 0.f, qo = 0.f;
         for (int k = l * 4; k < d; k += 256) {
             const f32x4 vv = *reinterpret_cast<const f32x4 *>(s + k);
+            const f32x4 m4 = *reinterpret_cast<const f32x4 *>(mu + k);
             f16x4 h;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                h[e] = (_Float16)vv[e];
-                q = fmaf(vv[e], vv[e], q);
+                const float c = vv[e] - m4[e];  // x' = fl32(x - mu): what the image holds, rounded to fp16
+                h[e] = (_Float16)c;
+                q = fmaf(c, c, q);
+                qo = fmaf(vv[e], vv[e], qo);
             }
             *reinterpret_cast<f16x4 *>(hi + k) = h;
         }
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) q += __shfl_xor(q, off);
-        float nr = sqrtf(q) * 1.0001f;  // the norm only feeds an upper bound
+        for (int off = 32; off > 0; off >>= 1) {
+            q += __shfl_xor(q, off);
+            qo += __shfl_xor(qo, off);
+        }
+        float nr = sqrtf(q) * 1.0001f, nro = sqrtf(qo) * 1.0001f;  // the norms only feed an upper bound
         if (!(nr == nr)) nr = INFINITY;  // a NaN row must not hide from the fp16-trust test of the filter
+        if (!(nro == nro)) nro = INFINITY;
         mymax = fmaxf(mymax, nr);
+        mymaxo = fmaxf(mymaxo, nro);
     }
-    // ONE atomic per block (a single word saturates near 88 atomics/us)
-    if (l == 0) wmax[w] = mymax;
+    // ONE atomic per block and maximum (a single word saturates near 88 atomics/us)
+    if (l == 0) {
+        wmax[w] = mymax;
+        wmaxo[w] = mymaxo;
+    }
     __syncthreads();
     if (tid == 0) {
-        const float m = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
-        atomicMax(&H->xmax_bits, __builtin_bit_cast(unsigned int, m));
+        atomicMax(&H->xmax_bits, __builtin_bit_cast(unsigned int, fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]))));
+        atomicMax(&H->xmax_orig_bits, __builtin_bit_cast(unsigned int, fmaxf(fmaxf(wmaxo[0], wmaxo[1]), fmaxf(wmaxo[2], wmaxo[3]))));
     }
 }
 
@@ -352,6 +392,16 @@ __global__ void __launch_bounds__(256) round_rows_kernel(const float *src, int64
     }
 }
 
+// 2 eps of one query (header of this file); INFINITY when fp16 cannot be trusted (a norm above 65504, or not finite)
+struct EpsConst {
+    float rel_c, abs_c, chain_o;  // 1.25 (2^-10 + 1.1 d 2^-24 + 2^-23), 1.25 2^-24 sqrt(d), 1.25 d 2^-24
+};
+__device__ __forceinline__ float two_eps(const EpsConst &E, float qn, const DedupHeader *H) {
+    const float xc = __builtin_bit_cast(float, H->xmax_bits), xo = __builtin_bit_cast(float, H->xmax_orig_bits);
+    const bool ok = qn <= 65504.0f && xc <= 65504.0f && xo < 3.0e38f;  // false for NaN too
+    return ok ? 2.0f * (E.rel_c * qn * xc + E.abs_c * (qn + xc) + E.chain_o * qn * xo) : INFINITY;
+}
+
 // ---- per-launch control block (device, zeroed before every launch chunk) ------------------------------
 struct FastCtl {
     unsigned int win_arrived;  // workgroups that finished a corpus window (monotonic over the launch)
@@ -373,7 +423,7 @@ struct FastParams {
     int Ws;              // corpus tiles per split per window (a window is S * Ws tiles)
     int share;           // exchange thresholds between the splits of a query tile
     unsigned int wait_ticks;  // bound of the window wait (100 MHz ticks)
-    float slack_rel, slack_abs;
+    EpsConst eps;
     u64 *cand;     // [n_qt * S][FQ][F_C]
     u64 *part;     // [nq][S][k]
     float *thr_g;  // [n_qt * S][FQ] published thresholds (NaN = none yet)
@@ -382,7 +432,8 @@ struct FastParams {
     int *ovf_flag;  // [nq] 0 / 1
     int *ovf_list;  // [OVF_CAP]
     unsigned int *grp_ctr;  // [groups] tiles finished by the workgroups of an XCD group (tile_sync)
-    int prune_at;           // first prune of a list at this many rows (<= F_C - FP); later ones when the list has doubled
+    int prune_at;           // first scheduled prune once every list has this many rows (<= F_C - FP)
+    int prune_growth;       // percent: the tile count between scheduled prunes grows by this factor (150 = 1.5x)
     int tile_sync;          // keep the 32 workgroups of an XCD group on the same corpus tile step (bounded wait)
     unsigned int tile_wait_ticks;
     int dbg;                     // STAMPS kernel only, timing experiments (results WRONG): 1 = no insertions after window 4,
@@ -435,6 +486,38 @@ __device__ __forceinline__ float load_thr(const float *p) {
         t_last = now_;                                  \
     }
 
+// One wave prunes one list in place: the k-th largest approximate key by radix select, then every row whose approximate
+// score is below max(that score - 2 eps, thr_other) goes.  Returns the rows kept; *thr_out = the new filter threshold.
+template <int NPL>
+__device__ __forceinline__ int prune_list(u64 *cq, int n_c, int lp, int k, float eps2, float thr_other, float *thr_out) {
+    u64 keys[NPL];
+#pragma unroll
+    for (int j = 0; j < NPL; ++j) {
+        const int idx = j * 64 + lp;
+        keys[j] = (idx < n_c) ? cq[idx] : 0ull;
+    }
+    u64 T = 0;  // k-th largest approximate key
+    for (int bit = 63; bit >= 0; --bit) {
+        const u64 t2 = T | (1ull << bit);
+        int ge = 0;
+#pragma unroll
+        for (int j = 0; j < NPL; ++j) ge += __popcll(__ballot(keys[j] >= t2));
+        if (ge >= k) T = t2;
+    }
+    const float thr_new = fmaxf(key_score(T) - eps2, thr_other);
+    int base = 0;
+    const u64 lt_mask = (1ull << lp) - 1ull;
+#pragma unroll
+    for (int j = 0; j < NPL; ++j) {
+        const bool keep = keys[j] != 0ull && !(key_score(keys[j]) < thr_new);
+        const u64 m = __ballot(keep);
+        if (keep) cq[base + __popcll(m & lt_mask)] = keys[j];
+        base += __popcll(m);
+    }
+    *thr_out = thr_new;
+    return base;
+}
+
 template <bool STAMPS>
 __global__ void __launch_bounds__(F_THREADS, 2) ip_topk_fast_kernel(const FastParams P) {
     extern __shared__ __attribute__((aligned(16))) float smem_f[];
@@ -472,11 +555,9 @@ __global__ void __launch_bounds__(F_THREADS, 2) ip_topk_fast_kernel(const FastPa
         const uint32_t qg = q0 + tid;
         thr_s[tid] = -INFINITY;
         cnt_s[tid] = 0;
-        const float qn = qg < P.nq ? P.qnorm[qg] : 0.0f, xm = __builtin_bit_cast(float, P.hdr->xmax_bits);
         // the bound assumes no fp16 overflow: |x_j| <= ||x||, so norms <= 65504 exclude it.  Otherwise eps = inf
         // keeps every row until the buffer overflows and the query is redone by the exact scan.
-        const bool fp16_ok = qn <= 65504.0f && xm <= 65504.0f;  // false for NaN too
-        eps2_s[tid] = fp16_ok ? 2.0f * (P.slack_rel * qn * xm + P.slack_abs * (qn + xm)) : INFINITY;
+        eps2_s[tid] = two_eps(P.eps, qg < P.nq ? P.qnorm[qg] : 0.0f, P.hdr);
     }
 
     // ---- main loop: the ping-pong pipeline of pipe256.h, streamed across this workgroup's corpus tiles ----
@@ -501,14 +582,16 @@ __global__ void __launch_bounds__(F_THREADS, 2) ip_topk_fast_kernel(const FastPa
             }
     }
     const int NK = d / FK;
-    // Per-query prune trigger.  The filter threshold is only as fresh as the last prune, and for most of the scan the
-    // insertion rate is (rows kept at the last prune) / (rows seen at the last prune) per row: waiting for a full buffer
-    // (1,792 rows) lets the rows seen grow 6.6x between prunes and has ~1 insertion per (wave, query group) per tile.
-    // Pruning when the buffer has doubled keeps the threshold within 2x of fresh at ~13 prunes per list.
-    int *trig_s = cnt_s + FQ;
-    int *epoch_s = trig_s + FQ;  // last tile (1-based) in which some wave asked for a prune
-    if (tid < FQ) trig_s[tid] = min(F_C - FP, P.prune_at);
+    // Prune schedule.  The filter threshold is only as fresh as the last prune, and for most of the scan the insertion
+    // rate is (rows kept at the last prune) / (rows seen at the last prune) per row: waiting for a full buffer (1,792
+    // rows) lets the rows seen grow 6.6x between prunes and has ~1 insertion per (wave, query group) per tile.  Every
+    // list of the workgroup is therefore pruned at the SAME geometrically spaced tile counts (x P.prune_growth / 100:
+    // ~24 episodes over 17 k tiles at 1.5x): thresholds stay within 1.5x of fresh, and because every workgroup of the
+    // launch follows the same schedule the episodes (a vmcnt(0) drain + ~0.3 ms of selection) coincide instead of
+    // making a different workgroup the straggler of every window.  A buffer that fills up in between is pruned at once.
+    int *epoch_s = cnt_s + FQ;  // last tile (1-based) in which some wave asked for an unscheduled prune
     if (tid == 0) *epoch_s = 0;
+    int n_done = 0, next_sched = max(1, (P.prune_at + FP - 1) / FP);
 
     // tiles of this split / of split 0 (the longest sequence) over the whole scan: the tile-step counter of the XCD
     // group must see the same number of arrivals from every member
@@ -628,19 +711,22 @@ __global__ void __launch_bounds__(F_THREADS, 2) ip_topk_fast_kernel(const FastPa
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         STAMP(a_filter)
+        ++n_done;
+        const bool sched = n_done == next_sched;  // uniform
+        if (sched) next_sched = max(next_sched + 1, (int)(((long long)next_sched * P.prune_growth) / 100));
         {
-            const int c32 = cnt_s[w * 32 + (l & 31)], g32 = trig_s[w * 32 + (l & 31)];
-            if (__ballot(c32 > g32) != 0ull && l == 0) *epoch_s = t + 1;
+            const int c32 = cnt_s[w * 32 + (l & 31)];
+            if (__ballot(c32 > F_C - FP) != 0ull && l == 0) *epoch_s = t + 1;
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        if (*epoch_s == t + 1) {  // block-uniform
+        if (sched || *epoch_s == t + 1) {  // block-uniform
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             int lp = l;  // laundered like lf above: keeps the 32 buffer positions j * 64 + lane out of the tile loop's registers
             asm volatile("" : "+v"(lp));
             // queries of this wave whose buffer passed its trigger (lane q < 32 looks at query w * 32 + q)
-            u64 need = __ballot(lp < 32 && cnt_s[w * 32 + (lp & 31)] > trig_s[w * 32 + (lp & 31)]);
+            u64 need = __ballot(lp < 32 && cnt_s[w * 32 + (lp & 31)] > (sched ? P.k + 32 : F_C - FP));
             while (need) {
                 const int qq = __builtin_ctzll(need);
                 need &= need - 1;
@@ -648,37 +734,18 @@ __global__ void __launch_bounds__(F_THREADS, 2) ip_topk_fast_kernel(const FastPa
                 const int n_c = __builtin_amdgcn_readfirstlane(cnt_s[ql]);
                 {
                     u64 *cq = cand + (size_t)ql * F_C;
-                    u64 keys[F_NPL];
-#pragma unroll
-                    for (int j = 0; j < F_NPL; ++j) {
-                        const int idx = j * 64 + lp;
-                        keys[j] = (idx < n_c) ? cq[idx] : 0ull;
-                    }
-                    u64 T = 0;  // k-th largest approximate key
-                    for (int bit = 63; bit >= 0; --bit) {
-                        const u64 t2 = T | (1ull << bit);
-                        int ge = 0;
-#pragma unroll
-                        for (int j = 0; j < F_NPL; ++j) ge += __popcll(__ballot(keys[j] >= t2));
-                        if (ge >= P.k) T = t2;
-                    }
-                    float thr_new = key_score(T) - eps2_s[ql];
+                    float thr_other = -INFINITY;
                     if (P.share) {  // what the other splits of this query have established is just as valid here
                         float o = (lp < P.S && lp != split) ? load_thr(thr_tile + (size_t)lp * FQ + ql) : -INFINITY;
 #pragma unroll
                         for (int off = 16; off > 0; off >>= 1) o = fmaxf(o, __shfl_xor(o, off));  // S <= 32; NaN = none
-                        o = __shfl(o, 0);
-                        thr_new = fmaxf(thr_new, o);
+                        thr_other = __shfl(o, 0);
                     }
-                    int base = 0;
-                    const u64 lt_mask = (1ull << lp) - 1ull;
-#pragma unroll
-                    for (int j = 0; j < F_NPL; ++j) {
-                        const bool keep = keys[j] != 0ull && !(key_score(keys[j]) < thr_new);
-                        const u64 m = __ballot(keep);
-                        if (keep) cq[base + __popcll(m & lt_mask)] = keys[j];
-                        base += __popcll(m);
-                    }
+                    float thr_new;
+                    int base;  // (scheduled prunes see a few hundred rows: 8 keys per lane instead of 32)
+                    if (n_c <= 8 * 64) base = prune_list<8>(cq, n_c, lp, P.k, eps2_s[ql], thr_other, &thr_new);
+                    else if (n_c <= 16 * 64) base = prune_list<16>(cq, n_c, lp, P.k, eps2_s[ql], thr_other, &thr_new);
+                    else base = prune_list<F_NPL>(cq, n_c, lp, P.k, eps2_s[ql], thr_other, &thr_new);
                     if (lp == 0) {
                         if (base > F_C - FP) {  // more than 1,792 rows inside one 2 eps band: this query is redone exactly
                             if (atomicExch(&P.ovf_flag[q0 + ql], 1) == 0) {
@@ -688,7 +755,6 @@ __global__ void __launch_bounds__(F_THREADS, 2) ip_topk_fast_kernel(const FastPa
                             base = F_C - FP;
                         }
                         cnt_s[ql] = base;
-                        trig_s[ql] = min(F_C - FP, max(2 * base, base + 128));
                         thr_s[ql] = thr_new;
                         if (P.share) __hip_atomic_store(thr_mine + ql, thr_new, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
@@ -778,7 +844,7 @@ struct RescoreParams {
     u64 *part;           // [nq][S][k]
     uint32_t nq;
     int d, k, S;
-    float slack_rel, slack_abs;
+    EpsConst eps;
 };
 constexpr int RS_CHUNK = 256;            // floats of a row staged per step
 constexpr int RS_STRIDE = RS_CHUNK + 4;  // floats between the staged pieces of consecutive rows
@@ -803,9 +869,7 @@ __global__ void __launch_bounds__(64) rescore_kernel(const RescoreParams P) {
     u64 *dst = P.part + ((size_t)qg * P.S + split) * (size_t)P.k;
     const float *qsrc = P.q32 + (size_t)qg * d;
     for (int k4 = l * 4; k4 < d; k4 += 256) *reinterpret_cast<f32x4 *>(qrow_lds + k4) = *reinterpret_cast<const f32x4 *>(qsrc + k4);
-    const float qn = P.qnorm[qg], xm = __builtin_bit_cast(float, P.hdr->xmax_bits);
-    const bool fp16_ok = qn <= 65504.0f && xm <= 65504.0f;
-    const float eps2 = fp16_ok ? 2.0f * (P.slack_rel * qn * xm + P.slack_abs * (qn + xm)) : INFINITY;  // as in the filter kernel
+    const float eps2 = two_eps(P.eps, P.qnorm[qg], P.hdr);  // as in the filter kernel
     const u64 lt_mask = (1ull << l) - 1ull;
     u64 keys[F_NPL];
 #pragma unroll
@@ -992,9 +1056,14 @@ int ip_index_build(const float *d_x, int64_t n, int d, void *d_index, size_t ind
     uint8_t *cls = reinterpret_cast<uint8_t *>(base + L.cls_off);
     uint32_t *blk = reinterpret_cast<uint32_t *>(base + L.blk_off);
     u64 *samp = reinterpret_cast<u64 *>(base + L.samp_off);
+    float *mu = reinterpret_cast<float *>(base + L.mu_off);
+    float *part = reinterpret_cast<float *>(base + L.part_off);
     const bool dedup = env_int("ANCE_FAST_DEDUP", 1) != 0;
+    const int center = env_int("ANCE_FAST_CENTER", 1) != 0;
     ProfScope ps(PC_PLAN, st);
     (void)hipMemsetAsync(H, 0, 256, st);
+    hipLaunchKernelGGL(idx_colsum_kernel, dim3((unsigned)L.n_part), dim3(256), 0, st, d_x, n, d, part);
+    hipLaunchKernelGGL(idx_mean_kernel, dim3((unsigned)((d + 255) / 256)), dim3(256), 0, st, part, L.n_part, n, d, center, mu);
     if (dedup) {
         hipLaunchKernelGGL(idx_sample_hash_kernel, dim3(IDX_SAMPLES / 4), dim3(256), 0, st, d_x, n, d, samp);
         hipLaunchKernelGGL(idx_find_classes_kernel, dim3(1), dim3(256), 0, st, samp, n, H);
@@ -1003,8 +1072,8 @@ int ip_index_build(const float *d_x, int64_t n, int d, void *d_index, size_t ind
         hipLaunchKernelGGL(idx_count_kernel, dim3((unsigned)L.nb), dim3(256), 0, st, n, L.nb, H, cls, blk);
         hipLaunchKernelGGL(idx_scan_kernel, dim3(1), dim3(1024), 0, st, L.nb, H, blk);
     }
-    hipLaunchKernelGGL(idx_compact_round_kernel, dim3((unsigned)L.nb), dim3(256), 0, st, d_x, n, d, L.nb, H, cls, blk, x2, live2row,
-                       members);
+    hipLaunchKernelGGL(idx_compact_round_kernel, dim3((unsigned)L.nb), dim3(256), 0, st, d_x, n, d, L.nb, H, cls, blk, mu, x2,
+                       live2row, members);
     return check_launch("ance_ip_index_build");
 }
 
@@ -1068,11 +1137,15 @@ int ip_topk_fast(const float *d_x, int64_t n, int64_t row_base, const void *d_in
             return check_launch("rescore attr");
         attr_done = true;
     }
-    const float slack_rel = 1.25f * (9.765625e-4f + 2.1f * d * 5.9604645e-8f);
-    const float slack_abs = 1.25f * 5.9604645e-8f * sqrtf((float)d);
+    EpsConst eps;
+    eps.rel_c = 1.25f * (9.765625e-4f + 1.1f * d * 5.9604645e-8f + 1.1920929e-7f);
+    eps.abs_c = 1.25f * 5.9604645e-8f * sqrtf((float)d);
+    eps.chain_o = 1.25f * d * 5.9604645e-8f;
     const int share = env_int("ANCE_FAST_SHARE", 1);
     const int wait_us = env_int("ANCE_FAST_WINDOW_WAIT_US", 200);
     const int prune_at = env_int("ANCE_FAST_PRUNE_AT", 512);
+    int prune_growth = env_int("ANCE_FAST_PRUNE_GROWTH", 150);
+    if (prune_growth < 105) prune_growth = 105;
     const int tile_sync = env_int("ANCE_FAST_TILE_SYNC", 0);
     const int tile_wait_us = env_int("ANCE_FAST_TILE_WAIT_US", 30);
     unsigned long long *stamps = g_fast_stamps;  // measurement hook (ance_debug_search_stamps)
@@ -1091,10 +1164,12 @@ int ip_topk_fast(const float *d_x, int64_t n, int64_t row_base, const void *d_in
         P.nq = (uint32_t)nqc; P.d = d; P.k = k; P.S = pl.S; P.Ws = pl.Ws;
         P.n_qt = (int)((nqc + FQ - 1) / FQ);
         P.share = share && pl.S > 1; P.wait_ticks = (unsigned)(wait_us > 0 ? wait_us * 100 : 0);
-        P.slack_rel = slack_rel; P.slack_abs = slack_abs; P.cand = cand; P.part = part; P.thr_g = thr_g; P.ctl = ctl;
+        P.eps = eps; P.cand = cand; P.part = part; P.thr_g = thr_g; P.ctl = ctl;
         P.ovf_flag = ovf_flag; P.ovf_list = ovf_list; P.cnt_g = cnt_g;
         P.grp_ctr = reinterpret_cast<unsigned int *>(ovf_list + OVF_CAP);
         P.prune_at = prune_at > k + 64 ? prune_at : k + 64;
+        if (P.prune_at > F_C - FP) P.prune_at = F_C - FP;
+        P.prune_growth = prune_growth;
         P.tile_sync = tile_sync; P.tile_wait_ticks = (unsigned)(tile_wait_us > 0 ? tile_wait_us * 100 : 0);
         P.stamps = stamps; P.dbg = env_int("ANCE_FAST_DEBUG", 0);
         const int gq = 32 / pl.S;
@@ -1108,7 +1183,7 @@ int ip_topk_fast(const float *d_x, int64_t n, int64_t row_base, const void *d_in
         {
             RescoreParams R;
             R.q32 = P.q32; R.x32 = d_x; R.qnorm = qn; R.hdr = H; R.live2row = P.live2row; R.cand = cand; R.cnt_g = cnt_g; R.thr_g = thr_g;
-            R.part = part; R.nq = P.nq; R.d = d; R.k = k; R.S = pl.S; R.slack_rel = slack_rel; R.slack_abs = slack_abs;
+            R.part = part; R.nq = P.nq; R.d = d; R.k = k; R.S = pl.S; R.eps = eps;
             ProfScope ps(PC_RESCORE, st);
             hipLaunchKernelGGL(rescore_kernel, dim3((unsigned)(P.n_qt * pl.S * FQ)), dim3(64), rescore_lds_bytes(d), st, R);
         }

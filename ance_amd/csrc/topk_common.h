@@ -69,10 +69,10 @@ __device__ __forceinline__ void bitonic_sort_desc(u64 *s, int P2) {
 constexpr int DEDUP_MAXC = 4;       // classes of bit-identical rows collapsed per shard
 constexpr int DEDUP_MEMCAP = 1024;  // member ids kept per class (the smallest ones: no list needs more than k)
 struct DedupHeader {                // first 256 bytes of a search image
-    unsigned int xmax_bits;         // max row norm (float bits; +inf when a row norm is not finite)
+    unsigned int xmax_bits;         // max norm of the CENTRED rows x - mu the fp16 image holds (float bits; +inf when not finite)
     unsigned int n_live;            // rows of the image (duplicates collapsed)
     int n_classes;
-    int pad0;
+    unsigned int xmax_orig_bits;    // max norm of the rows themselves (the exact chain's own rounding scales with it)
     unsigned int guess[DEDUP_MAXC]; // sampled row that defines the class
     unsigned int rep[DEDUP_MAXC];   // smallest row id of the class: stays in the image
     unsigned int csize[DEDUP_MAXC]; // members besides the representative

@@ -135,7 +135,9 @@ def full_refresh(a):
                                  negative_sample=a.negative_sample, ann_chunk_factor=1, ann_measure_topk_mrr=False,
                                  model_type="rdot_nll", max_seq_length=a.seq_len, max_query_length=64, device=dev,
                                  max_tokens=a.max_tokens, timings=timings)
+    import logging
     import random
+    logging.basicConfig(format="%(asctime)s %(name)s %(message)s", level=logging.INFO, stream=sys.stderr)
     random.seed(0)
     t0 = time.perf_counter()
     train_pos, dev_pos = negatives.load_positive_ids(data)

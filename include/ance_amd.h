@@ -87,6 +87,8 @@ size_t ance_ip_topk_workspace_bytes(int64_t n, int64_t nq, int d, int k);
  *   ANCE_FAST_WINDOW_WAIT_US     bound of the wait at a window boundary (default 200, 0 = none)
  *   ANCE_FAST_SHARE=0            do not exchange thresholds between the splits of a query
  *   ANCE_FAST_DEDUP=0            do not collapse duplicate classes when an image is built
+ *   ANCE_FAST_CENTER=0           do not centre the fp16 image on the shard's mean row (the filter's error
+ *                                slack then scales with |x| instead of |x - mean|)
  */
 int ance_ip_topk(const float *d_x, int64_t n, int64_t row_base, const float *d_q, int64_t nq, int d, int k,
                  float *d_out_d, int64_t *d_out_i, void *d_workspace, size_t workspace_bytes, void *stream);
@@ -99,8 +101,8 @@ int ance_ip_topk(const float *d_x, int64_t n, int64_t row_base, const float *d_q
  *   ance_ip_index_build(d_x, n, d, d_index, bytes, stream)
  *   ance_ip_topk_indexed(d_x, n, row_base, d_index, ...)   with ance_ip_topk_indexed_workspace_bytes
  * The image is valid for exactly the (d_x, n, d) it was built from; d_x must stay alive and unchanged
- * (the exact re-scoring reads the fp32 rows).  Contents: fp16 rows (n d 2 bytes), row map, duplicate
- * classes.  Results are those of ance_ip_topk, bit for bit.
+ * (the exact re-scoring reads the fp32 rows).  Contents: the shard's mean row, fp16(row - mean) for every
+ * row kept (n d 2 bytes), row map, duplicate classes.  Results are those of ance_ip_topk, bit for bit.
  */
 size_t ance_ip_index_bytes(int64_t n, int d);
 int ance_ip_index_build(const float *d_x, int64_t n, int d, void *d_index, size_t index_bytes, void *stream);

@@ -464,3 +464,66 @@ def test_dedup_at_scale_is_not_slower():
         Do, Io = search_ref.flat_ip_topk_chain(xs, q[r:r + 1].cpu().numpy(), k)
         assert np.array_equal(rows[Io[0]], I[r]), r
         assert np.array_equal(Do[0], D[r]), r
+
+
+def _encoder_like(rng, n, spread=0.12):
+    """rows of one encoder: a large common component + small deviations (random-init roberta-base gives cosine 0.99
+    between any two passages, scores 737 +- 1.7): un-centred, 2 eps of the fp16 filter is wider than the whole score
+    distribution."""
+    c = rng.standard_normal(768).astype(np.float32)
+    c = (c / np.linalg.norm(c) * np.sqrt(768.0)).astype(np.float32)
+    x = (c[None, :] + spread * rng.standard_normal((n, 768))).astype(np.float32)
+    return x, c
+
+
+def test_rows_with_a_large_common_component(monkeypatch):
+    rng = np.random.default_rng(50)
+    x, c = _encoder_like(rng, 80000)
+    x[70000] = x[5]
+    q = (c[None, :] + 0.12 * rng.standard_normal((301, 768))).astype(np.float32)
+    q[300] = x[5]
+    D1, I1 = _check_exact("common_component", x, q, 200)
+    monkeypatch.setenv("ANCE_FAST_CENTER", "0")  # un-centred: every query overflows and is redone by the scan -- same bits
+    D2, I2 = _search(x, q, 200)
+    assert np.array_equal(I1, I2) and np.array_equal(D1, D2)
+
+
+def test_common_component_stays_on_the_fast_path():
+    """2 M encoder-like rows: with the centred image the launch must not fall back to the exact scan (it did for every
+    query before): compare the time with a corpus of LayerNorm-distributed rows of the same size."""
+    import time
+    import torch
+    from ance_amd.index import FlatIPIndex
+    g = torch.Generator(device="cuda").manual_seed(51)
+    n, nq, k = 2_000_000, 8192, 200
+    c = torch.randn((768,), generator=g, device="cuda")
+    c = c / c.norm() * (768.0 ** 0.5)
+
+    def timed(x, q):
+        idx = FlatIPIndex(768)
+        idx.add(x)
+        idx.search(q[:256], k)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        D, I = idx.search(q, k)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0, D, I
+
+    xl = torch.nn.functional.layer_norm(torch.randn((n, 768), generator=g, device="cuda"), (768,))
+    ql = torch.nn.functional.layer_norm(torch.randn((nq, 768), generator=g, device="cuda"), (768,))
+    t_ln, _, _ = timed(xl, ql)
+    del xl
+    xe = c[None, :] + 0.12 * torch.randn((n, 768), generator=g, device="cuda")
+    qe = c[None, :] + 0.12 * torch.randn((nq, 768), generator=g, device="cuda")
+    t_enc, D, I = timed(xe, qe)
+    _diag("common_component_scale", t_ln=t_ln, t_enc=t_enc)
+    assert t_enc < 1.5 * t_ln, (t_enc, t_ln)
+    # spot check against the oracle on the rows that can matter
+    from oracle import search_ref
+    I = I.cpu().numpy()
+    D = D.cpu().numpy()
+    samp = torch.randint(0, n, (20000,), generator=torch.Generator().manual_seed(3)).numpy()
+    for r in (0, 4000, 8191):
+        rows = np.unique(np.concatenate([I[r], samp]))
+        Do, Io = search_ref.flat_ip_topk_chain(xe[torch.from_numpy(rows).cuda()].cpu().numpy(), qe[r:r + 1].cpu().numpy(), k)
+        assert np.array_equal(rows[Io[0]], I[r]) and np.array_equal(Do[0], D[r])
