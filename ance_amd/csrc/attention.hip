@@ -9,6 +9,11 @@
 // exchange with lane ^ 32 per key block.  The C-layout of S^T (lane group g holds keys 4g..4g+3,
 // 8+4g.. of every 16) is consumed DIRECTLY as the B operand of O^T = V^T . P^T; V arrives already
 // transposed (key-contiguous) from the V^T GEMM epilogue, so no transpose is ever performed here.
+//
+// Measured and rejected (round 2): a workgroup owning 2-12 consecutive heads of a sequence with the next head's K / V^T / Q
+// loads software-pipelined behind the current head's compute (48 more VGPRs: 2 workgroups per CU instead of 4) --
+// 126-148 us per launch at the bench shape against 117 us for this kernel: the launch is bound by the dependent
+// MFMA -> softmax -> MFMA chain inside each wave, which only residency (waves per SIMD) hides, not by the staging latency.
 #include "common.h"
 #include "attention.h"
 
@@ -19,6 +24,87 @@ constexpr int HD = 64;          // head dim
 constexpr int ATT_THREADS = 256;
 
 __device__ __forceinline__ int kswz(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
+
+// One 32-query block (this wave's) of one (sequence, head) against all keys staged in LDS: online softmax in fp32,
+// P in fp16, output rows written to ctx.  qf = the block's Q fragments (B operand layout).
+__device__ __forceinline__ void attend_qblock(const AttnArgs &A, const _Float16 *Ks, const _Float16 *Vs, const f16x8 (&qf)[4], int s,
+                                              int h, int tok0, int T, int Tk, int vld, int qb0, int q_end, int g, int i) {
+    const int nkb = Tk >> 5;
+    float m_run = -INFINITY, l_run = 0.0f;
+    f32x16 o0 = {0}, o1 = {0};
+    for (int kb = 0; kb < nkb; ++kb) {
+        const int krow = kb * 32 + i;
+        const int ksw = (krow >> 1) & 7;
+        f32x16 st = {0};
+#pragma unroll
+        for (int sx = 0; sx < 4; ++sx) {
+            const f16x8 kf = *reinterpret_cast<const f16x8 *>(Ks + krow * HD + (((4 * g + sx) ^ ksw) * 8));
+            st = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[sx], st, 0, 0, 0);
+        }
+        // st[r] = score(key kb*32 + (r&3) + 8 (r>>2) + 4 g, query i)   (Q already carries 1/8)
+        const int key_base = kb * 32 + 4 * g;
+        float bm = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = key_base + (r & 3) + 8 * (r >> 2);
+            st[r] = key < T ? st[r] : -INFINITY;
+            bm = fmaxf(bm, st[r]);
+        }
+        bm = fmaxf(bm, __shfl_xor(bm, 32));
+        const float m_new = fmaxf(m_run, bm);   // finite: key 0 of block 0 is always real
+        const float alpha = __expf(m_run - m_new);
+        float psum = 0.0f;
+        float p[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            p[r] = __expf(st[r] - m_new);
+            psum += p[r];
+        }
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            o0[r] *= alpha;
+            o1[r] *= alpha;
+        }
+        // P^T fragments (B operand of O^T = V^T P^T): k-step u covers keys 16u..16u+15; this lane
+        // group owns keys 16u + 4g + {0..3} and 16u + 8 + 4g + {0..3} = registers 8u..8u+7.
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            f16x8 pf;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pf[j] = (_Float16)p[8 * u + j];
+            const int kc = kb * 32 + 16 * u + 4 * g;
+            const _Float16 *v0 = Vs + i * vld + kc;
+            const _Float16 *v1 = Vs + (i + 32) * vld + kc;
+            const f16x4 a0 = *reinterpret_cast<const f16x4 *>(v0);
+            const f16x4 a1 = *reinterpret_cast<const f16x4 *>(v0 + 8);
+            const f16x4 c0 = *reinterpret_cast<const f16x4 *>(v1);
+            const f16x4 c1 = *reinterpret_cast<const f16x4 *>(v1 + 8);
+            const f16x8 vf0 = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+            const f16x8 vf1 = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
+            o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf0, pf, o0, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf1, pf, o1, 0, 0, 0);
+        }
+    }
+    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    const float inv = 1.0f / l_tot;
+    // O^T[d][query]: d = db*32 + (r&3) + 8 (r>>2) + 4 g  ->  4 consecutive d per (db, r>>2)
+    if (qb0 + i < q_end) {
+        const size_t orow = A.cls_only ? (size_t)s : (size_t)(tok0 + qb0 + i);
+        _Float16 *op = A.ctx + orow * A.ld_ctx + h * HD + 4 * g;
+#pragma unroll
+        for (int db = 0; db < 2; ++db) {
+            const f32x16 &o = db == 0 ? o0 : o1;
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                const f16x4 v = {(_Float16)(o[4 * rq + 0] * inv), (_Float16)(o[4 * rq + 1] * inv),
+                                 (_Float16)(o[4 * rq + 2] * inv), (_Float16)(o[4 * rq + 3] * inv)};
+                *reinterpret_cast<f16x4 *>(op + db * 32 + 8 * rq) = v;
+            }
+        }
+    }
+}
 
 __global__ void __launch_bounds__(ATT_THREADS, 4) attention_kernel(const AttnArgs A) {
     extern __shared__ __attribute__((aligned(16))) float smem_f[];
@@ -85,7 +171,6 @@ __global__ void __launch_bounds__(ATT_THREADS, 4) attention_kernel(const AttnArg
     }
     __syncthreads();
 
-    const int nkb = Tk >> 5;
     for (int qb0 = w * 32; qb0 < q_end; qb0 += 128) {
         if (qb0 != w * 32) {  // later query blocks of long sequences (the first one was prefetched above)
             const _Float16 *qp = A.qk + (size_t)(tok0 + min(qb0 + i, T - 1)) * A.ld_qk + h * HD + 32 * g;
@@ -93,82 +178,10 @@ __global__ void __launch_bounds__(ATT_THREADS, 4) attention_kernel(const AttnArg
             for (int sx = 0; sx < 4; ++sx) qf[sx] = *reinterpret_cast<const f16x8 *>(qp + sx * 8);
         }
 
-        float m_run = -INFINITY, l_run = 0.0f;
-        f32x16 o0 = {0}, o1 = {0};
-        for (int kb = 0; kb < nkb; ++kb) {
-            const int krow = kb * 32 + i;
-            const int ksw = (krow >> 1) & 7;
-            f32x16 st = {0};
-#pragma unroll
-            for (int sx = 0; sx < 4; ++sx) {
-                const f16x8 kf = *reinterpret_cast<const f16x8 *>(Ks + krow * HD + (((4 * g + sx) ^ ksw) * 8));
-                st = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[sx], st, 0, 0, 0);
-            }
-            // st[r] = score(key kb*32 + (r&3) + 8 (r>>2) + 4 g, query i)   (Q already carries 1/8)
-            const int key_base = kb * 32 + 4 * g;
-            float bm = -INFINITY;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = key_base + (r & 3) + 8 * (r >> 2);
-                st[r] = key < T ? st[r] : -INFINITY;
-                bm = fmaxf(bm, st[r]);
-            }
-            bm = fmaxf(bm, __shfl_xor(bm, 32));
-            const float m_new = fmaxf(m_run, bm);   // finite: key 0 of block 0 is always real
-            const float alpha = __expf(m_run - m_new);
-            float psum = 0.0f;
-            float p[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                p[r] = __expf(st[r] - m_new);
-                psum += p[r];
-            }
-            l_run = l_run * alpha + psum;
-            m_run = m_new;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                o0[r] *= alpha;
-                o1[r] *= alpha;
-            }
-            // P^T fragments (B operand of O^T = V^T P^T): k-step u covers keys 16u..16u+15; this lane
-            // group owns keys 16u + 4g + {0..3} and 16u + 8 + 4g + {0..3} = registers 8u..8u+7.
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                f16x8 pf;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) pf[j] = (_Float16)p[8 * u + j];
-                const int kc = kb * 32 + 16 * u + 4 * g;
-                const _Float16 *v0 = Vs + i * vld + kc;
-                const _Float16 *v1 = Vs + (i + 32) * vld + kc;
-                const f16x4 a0 = *reinterpret_cast<const f16x4 *>(v0);
-                const f16x4 a1 = *reinterpret_cast<const f16x4 *>(v0 + 8);
-                const f16x4 c0 = *reinterpret_cast<const f16x4 *>(v1);
-                const f16x4 c1 = *reinterpret_cast<const f16x4 *>(v1 + 8);
-                const f16x8 vf0 = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
-                const f16x8 vf1 = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
-                o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf0, pf, o0, 0, 0, 0);
-                o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf1, pf, o1, 0, 0, 0);
-            }
-        }
-        const float l_tot = l_run + __shfl_xor(l_run, 32);
-        const float inv = 1.0f / l_tot;
-        // O^T[d][query]: d = db*32 + (r&3) + 8 (r>>2) + 4 g  ->  4 consecutive d per (db, r>>2)
-        if (qb0 + i < q_end) {
-            const size_t orow = A.cls_only ? (size_t)s : (size_t)(tok0 + qb0 + i);
-            _Float16 *op = A.ctx + orow * A.ld_ctx + h * HD + 4 * g;
-#pragma unroll
-            for (int db = 0; db < 2; ++db) {
-                const f32x16 &o = db == 0 ? o0 : o1;
-#pragma unroll
-                for (int rq = 0; rq < 4; ++rq) {
-                    const f16x4 v = {(_Float16)(o[4 * rq + 0] * inv), (_Float16)(o[4 * rq + 1] * inv),
-                                     (_Float16)(o[4 * rq + 2] * inv), (_Float16)(o[4 * rq + 3] * inv)};
-                    *reinterpret_cast<f16x4 *>(op + db * 32 + 8 * rq) = v;
-                }
-            }
-        }
+        attend_qblock(A, Ks, Vs, qf, s, h, tok0, T, Tk, vld, qb0, q_end, g, i);
     }
 }
+
 
 }  // namespace
 

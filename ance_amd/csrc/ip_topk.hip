@@ -338,10 +338,12 @@ size_t exact_scan_fallback_bytes(int64_t n, int64_t nq, int k) {
     return pl.part_bytes + pl.cand_bytes + 256;
 }
 
-int exact_scan_fallback(const float *d_x, int64_t n, const float *d_q, int64_t nq, int d, int k, void *d_ws, const int *only_if,
-                        const int *nq_dev, const u64 **part_out, int *m_out, hipStream_t st) {
+int exact_scan_fallback(const float *d_x, int64_t n, const float *d_q, int64_t nq, int64_t nq_plan, int d, int k, void *d_ws,
+                        const int *only_if, const int *nq_dev, const u64 **part_out, int *m_out, hipStream_t st) {
+    // The plan (corpus splits, buffer layout) is the one the workspace was sized for -- nq_plan queries -- whatever the
+    // size of this chunk: a short last chunk planned on its own would choose more splits and outgrow the buffers.
     Plan pl;
-    if (!make_plan(n, nq, k, &pl) || nq > pl.qc) {
+    if (!make_plan(n, nq_plan, k, &pl) || nq_plan > pl.qc || nq > nq_plan) {
         set_last_error("exact_scan_fallback: chunk too large");
         return ANCE_E_INVALID;
     }

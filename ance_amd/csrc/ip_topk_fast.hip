@@ -1191,11 +1191,12 @@ int ip_topk_fast(const float *d_x, int64_t n, int64_t row_base, const void *d_in
         hipLaunchKernelGGL(gather_overflow_kernel, dim3(OVF_CAP), dim3(256), 0, st, ctl, ovf_list, d_q + (size_t)q0 * d, d, qfb, fb_slot);
         const u64 *fb_part = nullptr, *fball_part = nullptr;
         int fb_m = 0, fball_m = 0;
-        int rc = exact_scan_fallback(d_x, n, qfb, OVF_CAP, d, k, fb_ws, nullptr, &ctl->fb_nq, &fb_part, &fb_m, st);
+        int rc = exact_scan_fallback(d_x, n, qfb, OVF_CAP, OVF_CAP, d, k, fb_ws, nullptr, &ctl->fb_nq, &fb_part, &fb_m, st);
         if (rc) return rc;
         rc = launch_reduce_keys(fb_part, OVF_CAP, fb_m, k, fb_keys, &ctl->fb_nq, st);
         if (rc) return rc;
-        rc = exact_scan_fallback(d_x, n, d_q + (size_t)q0 * d, nqc, d, k, fball_ws, &ctl->fb_all, nullptr, &fball_part, &fball_m, st);
+        rc = exact_scan_fallback(d_x, n, d_q + (size_t)q0 * d, nqc, nq < pl.qc ? nq : pl.qc, d, k, fball_ws, &ctl->fb_all, nullptr,
+                                 &fball_part, &fball_m, st);
         if (rc) return rc;
         FinalizeAlt alt;
         alt.sel_all = &ctl->fb_all; alt.all_keys = fball_part; alt.all_m = fball_m;

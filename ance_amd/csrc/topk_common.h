@@ -189,9 +189,9 @@ int launch_reduce_keys(const u64 *keys, int nq_max, int m, int k, u64 *out, cons
 
 // exact fp32-MFMA scan of one query chunk (nq <= 65,536), device-side conditional: a no-op while *only_if == 0
 // (when given), over min(nq, *nq_dev) queries (when given); leaves m_out = S*k survivors per query at *part_out
-// inside the given workspace.
+// inside the given workspace, which exact_scan_fallback_bytes(n, nq_plan, k) sized (nq <= nq_plan).
 size_t exact_scan_fallback_bytes(int64_t n, int64_t nq, int k);
-int exact_scan_fallback(const float *d_x, int64_t n, const float *d_q, int64_t nq, int d, int k, void *d_ws, const int *only_if,
-                        const int *nq_dev, const u64 **part_out, int *m_out, hipStream_t st);
+int exact_scan_fallback(const float *d_x, int64_t n, const float *d_q, int64_t nq, int64_t nq_plan, int d, int k, void *d_ws,
+                        const int *only_if, const int *nq_dev, const u64 **part_out, int *m_out, hipStream_t st);
 
 }  // namespace ance

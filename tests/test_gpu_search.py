@@ -527,3 +527,18 @@ def test_common_component_stays_on_the_fast_path():
         rows = np.unique(np.concatenate([I[r], samp]))
         Do, Io = search_ref.flat_ip_topk_chain(xe[torch.from_numpy(rows).cuda()].cpu().numpy(), qe[r:r + 1].cpu().numpy(), k)
         assert np.array_equal(rows[Io[0]], I[r]) and np.array_equal(Do[0], D[r])
+
+
+def test_whole_chunk_redo_with_a_short_last_chunk(monkeypatch):
+    """6,980 queries (the MS MARCO dev set) = launch chunks of 4,096 + 2,884, every query overflowing (un-centred
+    encoder-like rows): the exact-scan redo of the SHORT chunk must run inside the buffers sized for the full one
+    (planned on its own it picks more corpus splits -- a memory fault at 2 M rows before the fix)."""
+    from oracle import search_ref
+    monkeypatch.setenv("ANCE_FAST_CENTER", "0")
+    rng = np.random.default_rng(52)
+    x, c = _encoder_like(rng, 60000)
+    q = (c[None, :] + 0.12 * rng.standard_normal((6980, 768))).astype(np.float32)
+    D, I = _search(x, q, 100)
+    pick = np.concatenate([np.arange(0, 40), np.arange(4090, 4130), np.arange(6940, 6980)])
+    Do, Io = search_ref.flat_ip_topk_chain(x, q[pick], 100)
+    assert np.array_equal(I[pick], Io) and np.array_equal(D[pick], Do)
