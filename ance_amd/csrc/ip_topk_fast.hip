@@ -34,14 +34,18 @@
 // and the second term is the same for every row of a query, so ranking by q . x' is ranking by q . x -- but |x'| is what the
 // fp16 rounding error scales with.  Embeddings of one encoder share a large common component (random-init roberta-base:
 // cosine 0.99 between any two passages, scores 737 +- 1.7): without the centring 2 eps is wider than the whole score
-// distribution and every query overflows.  With C the canonical fp32 chain score of (q, x), s~ the filter's score:
-//   rounding q and x' to fp16, normal range:   |q . x' - qh . xh| <= (2^-11 + 2^-11 + 2^-22) |q| |x'|
-//   fp32 accumulation inside / between MFMAs:  <= 1.1 d 2^-24 |q| |x'|
-//   x' = fl32(x - mu):                         <= 2^-24 |q| |x'|        (2^-23 budgeted)
-//   fp16 subnormal inputs, 2^-25 per element:  <= 2^-25 sqrt(d) (|q| + |x'|)
-//   the chain itself, C vs q . x:              <= d 2^-24 |q| |x|       (the un-centred norm)
-// |s~ - (C - q . mu)| <= eps = 1.25 * [ (2^-10 + 1.1 d 2^-24 + 2^-23) |q| max|x'| + 2^-24 sqrt(d) (|q| + max|x'|) + d 2^-24 |q| max|x| ]
-// (tests/test_eps_bound.py attacks it on the CPU).
+// distribution and every query overflows.  The queries get the same treatment: q = mq + dq with mq the mean query of the
+// call, q . x' = mq . x' + dq . x'; the first term is a per-ROW constant b (one fp32 pass over the shard per call, the
+// accumulators of a corpus tile start from it), and only dq meets the fp16 rounding.  With C the canonical fp32 chain score:
+//   rounding dq and x' to fp16, normal range:  |dq . x' - dqh . xh| <= (2^-11 + 2^-11 + 2^-22) |dq| |x'|
+//   fp32 accumulation inside / between MFMAs, starting from b:  <= 1.1 d 2^-24 (|dq| + |mq|) |x'|
+//   b = fl32 chain of mq . x':                 <= d 2^-24 |mq| |x'|
+//   x' = fl32(x - mu), dq = fl32(q - mq):      <= 2^-23 |q| |x'|
+//   fp16 subnormal inputs, 2^-25 per element:  <= 2^-25 sqrt(d) (|dq| + |x'|)
+//   the chain itself, C vs q . x:              <= d 2^-24 |q| |x|       (the un-centred norms)
+// |s~ - (C - q . mu)| <= eps = 1.25 * [ (2^-10 + 1.1 d 2^-24) |dq| X' + 2.1 d 2^-24 |mq| X' + 2^-23 |q| X' + 2^-24 sqrt(d) (|dq| + X') + d 2^-24 |q| X ]
+// with X' = max |x'|, X = max |x| (tests/test_eps_bound.py attacks it on the CPU).  The query mean is only used when it
+// is a sizeable part of the queries (|mq| > 0.05 X); otherwise mq = 0, dq = q, b = 0 and the bias pass is skipped.
 #include "common.h"
 #include "topk_common.h"
 #include "pipe256.h"
@@ -56,7 +60,7 @@ constexpr int F_STAGE_HALVES = 2 * F_OPER_HALVES;
 constexpr int F_THREADS = 512;
 constexpr int F_NPL = 32;
 constexpr int F_C = F_NPL * 64;  // 2048 buffered rows per (block, query); a tile can add 256
-constexpr size_t F_LDS_BYTES = (size_t)2 * F_STAGE_HALVES * sizeof(_Float16) + 3 * FQ * 4 + 16;
+constexpr size_t F_LDS_BYTES = (size_t)2 * F_STAGE_HALVES * sizeof(_Float16) + 3 * FQ * 4 + 16 + 2 * FP * 4;
 constexpr int F_MAX_D = 2048;    // block-end re-scoring keeps 8 fp32 query rows + 8 position lists in the stage area
 constexpr int F_MAX_K = 1024;
 constexpr int OVF_CAP = 1024;    // overflowing queries per launch chunk that are redone one by one
@@ -111,6 +115,52 @@ __global__ void __launch_bounds__(256) idx_mean_kernel(const float *part, int n_
     for (int p = 0; p < n_part; ++p) s += (double)part[(size_t)p * d + c];
     const float m = (float)(s / (double)n);
     mu[c] = (center && m == m && fabsf(m) < 3.0e38f) ? m : 0.0f;
+}
+
+// the mean query of a call: used only when it is a sizeable part of the queries (|mq| > 0.05 max|x|); decided on the device
+struct QueryStat {
+    float mq_norm;  // |mq| (0 when not used)
+    int use_bias;   // != 0: dq = q - mq goes through the MFMAs, b = mq . x' is added per row
+};
+__global__ void __launch_bounds__(256) query_mean_decide_kernel(float *mq, int d, const DedupHeader *H, QueryStat *qs) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (int c = threadIdx.x; c < d; c += 256) s += mq[c] * mq[c];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    const float nrm = sqrtf(red[0] + red[1] + red[2] + red[3]) * 1.0001f;
+    const float xo = __builtin_bit_cast(float, H->xmax_orig_bits);
+    const bool use = nrm == nrm && nrm < 3.0e38f && xo < 3.0e38f && nrm > 0.05f * xo;
+    __syncthreads();
+    if (!use)
+        for (int c = threadIdx.x; c < d; c += 256) mq[c] = 0.0f;
+    if (threadIdx.x == 0) {
+        qs->mq_norm = use ? nrm : 0.0f;
+        qs->use_bias = use ? 1 : 0;
+    }
+}
+
+// b[r] = mq . x'(image row r), x' = fl32(x - mu) recomputed from the fp32 shard row: one wave per image row
+__global__ void __launch_bounds__(256) row_bias_kernel(const float *x, int d, const DedupHeader *H, const uint32_t *live2row, const float *mu,
+                                                       const float *mq, const QueryStat *qs, float *bias) {
+    if (!qs->use_bias) return;
+    const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t n_live = H->n_live;
+    for (int64_t r = (int64_t)blockIdx.x * 4 + w; r < n_live; r += (int64_t)gridDim.x * 4) {
+        const float *s = x + (size_t)live2row[r] * d;
+        float acc = 0.f;
+        for (int k = l * 4; k < d; k += 256) {
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(s + k), m4 = *reinterpret_cast<const f32x4 *>(mu + k),
+                        q4 = *reinterpret_cast<const f32x4 *>(mq + k);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc = fmaf(q4[e], v[e] - m4[e], acc);
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+        if (l == 0) bias[r] = acc;
+    }
 }
 
 // one wave per sampled row: position-mixed 64-bit hash of the row's bits; low 11 bits carry the sample index
@@ -369,37 +419,48 @@ __global__ void __launch_bounds__(256) idx_compact_round_kernel(const float *x, 
     }
 }
 
-// fp16 rounding + row norm of the query chunk: one wave per row
-__global__ void __launch_bounds__(256) round_rows_kernel(const float *src, int64_t rows, int d, _Float16 *dst, float *norm) {
+// fp16(q - mq) + the norms of dq = q - mq and of q for the query chunk: one wave per row
+__global__ void __launch_bounds__(256) round_rows_kernel(const float *src, int64_t rows, int d, const float *mq, _Float16 *dst,
+                                                         float *norm_c, float *norm_o) {
     const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
     for (int64_t row = (int64_t)blockIdx.x * 4 + w; row < rows; row += (int64_t)gridDim.x * 4) {
         const float *s = src + (size_t)row * d;
         _Float16 *hi = dst + (size_t)row * d;
-        float q = 0.f;
+        float q = 0.f, qo = 0.f;
         for (int k = l * 4; k < d; k += 256) {
-            const f32x4 v = *reinterpret_cast<const f32x4 *>(s + k);
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(s + k), m4 = *reinterpret_cast<const f32x4 *>(mq + k);
             f16x4 h;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                h[j] = (_Float16)v[j];
-                q = fmaf(v[j], v[j], q);
+                const float c = v[j] - m4[j];
+                h[j] = (_Float16)c;
+                q = fmaf(c, c, q);
+                qo = fmaf(v[j], v[j], qo);
             }
             *reinterpret_cast<f16x4 *>(hi + k) = h;
         }
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) q += __shfl_xor(q, off);
-        if (l == 0) norm[row] = sqrtf(q) * 1.0001f;  // NaN stays NaN: the filter's trust test is false for it
+        for (int off = 32; off > 0; off >>= 1) {
+            q += __shfl_xor(q, off);
+            qo += __shfl_xor(qo, off);
+        }
+        if (l == 0) {  // NaN stays NaN: the filter's trust test is false for it
+            norm_c[row] = sqrtf(q) * 1.0001f;
+            norm_o[row] = sqrtf(qo) * 1.0001f;
+        }
     }
 }
 
 // 2 eps of one query (header of this file); INFINITY when fp16 cannot be trusted (a norm above 65504, or not finite)
 struct EpsConst {
-    float rel_c, abs_c, chain_o;  // 1.25 (2^-10 + 1.1 d 2^-24 + 2^-23), 1.25 2^-24 sqrt(d), 1.25 d 2^-24
+    float rel_c, acc_m, cen, abs_c, chain_o;  // 1.25 x: (2^-10 + 1.1 d 2^-24), 2.1 d 2^-24, 2^-23, 2^-24 sqrt(d), d 2^-24
 };
-__device__ __forceinline__ float two_eps(const EpsConst &E, float qn, const DedupHeader *H) {
+// qc = |q - mq|, qo = |q|
+__device__ __forceinline__ float two_eps(const EpsConst &E, float qc, float qo, const QueryStat *qs, const DedupHeader *H) {
     const float xc = __builtin_bit_cast(float, H->xmax_bits), xo = __builtin_bit_cast(float, H->xmax_orig_bits);
-    const bool ok = qn <= 65504.0f && xc <= 65504.0f && xo < 3.0e38f;  // false for NaN too
-    return ok ? 2.0f * (E.rel_c * qn * xc + E.abs_c * (qn + xc) + E.chain_o * qn * xo) : INFINITY;
+    const bool ok = qc <= 65504.0f && qo < 3.0e38f && xc <= 65504.0f && xo < 3.0e38f;  // false for NaN too
+    return ok ? 2.0f * (E.rel_c * qc * xc + E.acc_m * qs->mq_norm * xc + E.cen * qo * xc + E.abs_c * (qc + xc) + E.chain_o * qo * xo)
+              : INFINITY;
 }
 
 // ---- per-launch control block (device, zeroed before every launch chunk) ------------------------------
@@ -415,7 +476,9 @@ struct FastParams {
     const _Float16 *x2;  // [n_live, d] fp16 image rows
     const float *q32;    // [nq, d]
     const float *x32;    // [n, d] shard rows
-    const float *qnorm;  // [nq]
+    const float *qnorm_c, *qnorm_o;  // [nq] |q - mq|, |q|
+    const QueryStat *qstat;
+    const float *bias;   // [n_live + 256] mq . x' per image row (read only when qstat->use_bias)
     const DedupHeader *hdr;
     const uint32_t *live2row;
     uint32_t nq;
@@ -518,8 +581,12 @@ __device__ __forceinline__ int prune_list(u64 *cq, int n_c, int lp, int k, float
     return base;
 }
 
-template <bool STAMPS>
+// BIAS: the build that starts every corpus tile's accumulators from the per-row share of the mean query (header).  Both
+// builds are launched for every chunk and the one the device-side decision (QueryStat) did not pick returns at once: the
+// choice needs no host synchronisation, and the common case keeps the leaner kernel (the bias build is ~5 % slower).
+template <bool STAMPS, bool BIAS>
 __global__ void __launch_bounds__(F_THREADS, 2) ip_topk_fast_kernel(const FastParams P) {
+    if ((P.qstat->use_bias != 0) != BIAS) return;
     extern __shared__ __attribute__((aligned(16))) float smem_f[];
     _Float16 *smem = reinterpret_cast<_Float16 *>(smem_f);
     float *thr_s = smem_f + (2 * F_STAGE_HALVES) / 2;  // after the 128 KiB of stages: filter threshold t~ - 2 eps
@@ -557,7 +624,7 @@ __global__ void __launch_bounds__(F_THREADS, 2) ip_topk_fast_kernel(const FastPa
         cnt_s[tid] = 0;
         // the bound assumes no fp16 overflow: |x_j| <= ||x||, so norms <= 65504 exclude it.  Otherwise eps = inf
         // keeps every row until the buffer overflows and the query is redone by the exact scan.
-        eps2_s[tid] = two_eps(P.eps, qg < P.nq ? P.qnorm[qg] : 0.0f, P.hdr);
+        eps2_s[tid] = two_eps(P.eps, qg < P.nq ? P.qnorm_c[qg] : 0.0f, qg < P.nq ? P.qnorm_o[qg] : 0.0f, P.qstat, P.hdr);
     }
 
     // ---- main loop: the ping-pong pipeline of pipe256.h, streamed across this workgroup's corpus tiles ----
@@ -591,6 +658,18 @@ __global__ void __launch_bounds__(F_THREADS, 2) ip_topk_fast_kernel(const FastPa
     // making a different workgroup the straggler of every window.  A buffer that fills up in between is pruned at once.
     int *epoch_s = cnt_s + FQ;  // last tile (1-based) in which some wave asked for an unscheduled prune
     if (tid == 0) *epoch_s = 0;
+    // Per-row bias b = mq . x' of the corpus tile (header: the mean query's share of every score): two 1 KiB LDS slots,
+    // filled by ONE LDS-DMA of wave 0 a whole tile ahead -- the instruction is older than every staging DMA the pipeline
+    // counts, so the pipeline's own waits and barriers retire and publish it -- and read back as the accumulators' start.
+    float *bias_s = reinterpret_cast<float *>(epoch_s + 4);
+    int bbuf = 0;
+    auto stage_bias = [&](int tile, int buf) {
+        if (w == 0) {
+            int lb = l;  // (laundered: keeps the per-lane address out of the tile loop's live registers, see the filter)
+            asm volatile("" : "+v"(lb));
+            __builtin_amdgcn_global_load_lds((pipe_glb_t *)(P.bias + (size_t)tile * FP + lb * 4), (pipe_lds_t *)(bias_s + buf * FP), 16, 0, 0);
+        }
+    };
     int n_done = 0, next_sched = max(1, (P.prune_at + FP - 1) / FP);
 
     // tiles of this split / of split 0 (the longest sequence) over the whole scan: the tile-step counter of the XCD
@@ -613,6 +692,7 @@ __global__ void __launch_bounds__(F_THREADS, 2) ip_topk_fast_kernel(const FastPa
     int t = split * P.Ws, jw = 0, win = 0;
     bool have = t < n_tiles;
     if (have) {
+        if constexpr (BIAS) stage_bias(t, 0);
         pipe.S.rx0 = tile_rsrc(P.x2, (uint32_t)t * FP, n, d);
         pipe.S.rx1 = pipe.S.rx0;
         pipe.prologue();  // also publishes thr_s / cnt_s / eps2_s / epoch_s
@@ -635,10 +715,29 @@ __global__ void __launch_bounds__(F_THREADS, 2) ip_topk_fast_kernel(const FastPa
         pipe.S.rx0 = tile_rsrc(P.x2, p0, n, d);
         pipe.S.rx1 = tile_rsrc(P.x2, (uint32_t)tn * FP, n, d);
         f32x16 acc[2][4];
+        if constexpr (BIAS) {
+            if (have_n) stage_bias(tn, bbuf ^ 1);
+            // acc[x][y][4 rq + j] <- b[row p0 + wn*64 + x*32 + 8 rq + 4 g + j], the same for the four query groups y
+            int lb = l;
+            asm volatile("" : "+v"(lb));
+            const float *bs = bias_s + bbuf * FP + wn * 64 + 4 * (lb >> 5);
 #pragma unroll
-        for (int x = 0; x < 2; ++x)
+            for (int x = 0; x < 2; ++x)
 #pragma unroll
-            for (int y = 0; y < 4; ++y) acc[x][y] = f32x16{0};
+                for (int rq = 0; rq < 4; ++rq) {
+                    const f32x4 v = *reinterpret_cast<const f32x4 *>(bs + x * 32 + 8 * rq);
+#pragma unroll
+                    for (int y = 0; y < 4; ++y)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[x][y][4 * rq + j] = v[j];
+                }
+            bbuf ^= 1;
+        } else {
+#pragma unroll
+            for (int x = 0; x < 2; ++x)
+#pragma unroll
+                for (int y = 0; y < 4; ++y) acc[x][y] = f32x16{0};
+        }
         pipe.enter();
         if (have_n) pipe.tiles_streaming(NK, acc);
         else pipe.tiles_final(NK, acc);
@@ -835,7 +934,8 @@ __global__ void __launch_bounds__(F_THREADS, 2) ip_topk_fast_kernel(const FastPa
 // load instruction and ran at 1.3 TB/s -- and each lane runs the canonical fmaf chain (k ascending) over its row's
 // piece from LDS (row stride 1040 bytes: conflict-free ds_read_b128).  Exact keys stay in registers for the selection.
 struct RescoreParams {
-    const float *q32, *x32, *qnorm;
+    const float *q32, *x32, *qnorm_c, *qnorm_o;
+    const QueryStat *qstat;
     const DedupHeader *hdr;
     const uint32_t *live2row;
     const u64 *cand;     // [n_qt * S][FQ][F_C]
@@ -869,7 +969,7 @@ __global__ void __launch_bounds__(64) rescore_kernel(const RescoreParams P) {
     u64 *dst = P.part + ((size_t)qg * P.S + split) * (size_t)P.k;
     const float *qsrc = P.q32 + (size_t)qg * d;
     for (int k4 = l * 4; k4 < d; k4 += 256) *reinterpret_cast<f32x4 *>(qrow_lds + k4) = *reinterpret_cast<const f32x4 *>(qsrc + k4);
-    const float eps2 = two_eps(P.eps, P.qnorm[qg], P.hdr);  // as in the filter kernel
+    const float eps2 = two_eps(P.eps, P.qnorm_c[qg], P.qnorm_o[qg], P.qstat, P.hdr);  // as in the filter kernel
     const u64 lt_mask = (1ull << l) - 1ull;
     u64 keys[F_NPL];
 #pragma unroll
@@ -974,7 +1074,7 @@ __global__ void __launch_bounds__(256) gather_overflow_kernel(FastCtl *ctl, cons
 struct FastPlan {
     int S, Ws;
     int64_t qc;  // queries per launch
-    size_t q2_bytes, qn_bytes, cand_bytes, part_bytes, thr_bytes, cnt_bytes, flag_bytes, qfb_bytes, fbk_bytes, fb_bytes, fball_bytes;
+    size_t q2_bytes, qn_bytes, qctr_bytes, bias_bytes, cand_bytes, part_bytes, thr_bytes, cnt_bytes, flag_bytes, qfb_bytes, fbk_bytes, fb_bytes, fball_bytes;
 };
 
 int env_int(const char *name, int dflt) {
@@ -1005,7 +1105,9 @@ bool make_fast_plan(int64_t n, int64_t nq, int d, int k, FastPlan *pl) {
     if (Wt <= 0 || Wt > n_tiles) Wt = n_tiles;
     pl->Ws = (Wt + S - 1) / S;
     pl->q2_bytes = align_up((size_t)pl->qc * d * sizeof(_Float16), 256);
-    pl->qn_bytes = align_up((size_t)pl->qc * sizeof(float), 256);
+    pl->qn_bytes = align_up((size_t)2 * pl->qc * sizeof(float), 256);  // |q - mq| and |q|
+    pl->qctr_bytes = 256 + align_up((size_t)d * sizeof(float), 256) + align_up((size_t)1024 * d * sizeof(float), 256);  // QueryStat, mq, partials
+    pl->bias_bytes = align_up(((size_t)n + FP) * sizeof(float), 256);
     pl->cand_bytes = (size_t)qct * S * FQ * F_C * sizeof(u64);
     pl->part_bytes = align_up((size_t)pl->qc * S * k * sizeof(u64), 256);
     pl->thr_bytes = align_up((size_t)qct * S * FQ * sizeof(float) + (size_t)pl->qc * sizeof(int), 256);  // thr_g + fb_slot (0xFF fill)
@@ -1020,7 +1122,7 @@ bool make_fast_plan(int64_t n, int64_t nq, int d, int k, FastPlan *pl) {
 }
 
 size_t fast_search_bytes(const FastPlan &pl) {
-    return 256 + pl.q2_bytes + pl.qn_bytes + pl.part_bytes + pl.cand_bytes + pl.thr_bytes + pl.cnt_bytes + pl.flag_bytes + pl.qfb_bytes +
+    return 256 + pl.q2_bytes + pl.qn_bytes + pl.qctr_bytes + pl.bias_bytes + pl.part_bytes + pl.cand_bytes + pl.thr_bytes + pl.cnt_bytes + pl.flag_bytes + pl.qfb_bytes +
            pl.fbk_bytes + pl.fb_bytes + pl.fball_bytes;
 }
 
@@ -1098,6 +1200,12 @@ int ip_topk_fast(const float *d_x, int64_t n, int64_t row_base, const void *d_in
     char *p = reinterpret_cast<char *>(align_up((uintptr_t)d_workspace, 256));
     _Float16 *q2 = reinterpret_cast<_Float16 *>(p); p += pl.q2_bytes;
     float *qn = reinterpret_cast<float *>(p); p += pl.qn_bytes;
+    float *qn_o = qn + pl.qc;
+    QueryStat *qstat = reinterpret_cast<QueryStat *>(p);
+    float *mq = reinterpret_cast<float *>(p + 256);
+    float *qpart = reinterpret_cast<float *>(p + 256 + align_up((size_t)d * sizeof(float), 256));
+    p += pl.qctr_bytes;
+    float *bias = reinterpret_cast<float *>(p); p += pl.bias_bytes;
     u64 *part = reinterpret_cast<u64 *>(p); p += pl.part_bytes;
     u64 *cand = reinterpret_cast<u64 *>(p); p += pl.cand_bytes;
     char *ff_area = p; p += pl.thr_bytes;    // 0xFF-filled per chunk
@@ -1127,10 +1235,13 @@ int ip_topk_fast(const float *d_x, int64_t n, int64_t row_base, const void *d_in
 
     static bool attr_done = false;
     if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(ip_topk_fast_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)F_LDS_BYTES) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void *>(ip_topk_fast_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)F_LDS_BYTES) != hipSuccess)
+        bool ok = true;
+        for (const void *fn : {reinterpret_cast<const void *>(ip_topk_fast_kernel<false, false>),
+                               reinterpret_cast<const void *>(ip_topk_fast_kernel<false, true>),
+                               reinterpret_cast<const void *>(ip_topk_fast_kernel<true, false>),
+                               reinterpret_cast<const void *>(ip_topk_fast_kernel<true, true>)})
+            ok = ok && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)F_LDS_BYTES) == hipSuccess;
+        if (!ok)
             return check_launch("ip_topk_fast attr");
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(rescore_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)rescore_lds_bytes(F_MAX_D)) != hipSuccess)
@@ -1138,9 +1249,26 @@ int ip_topk_fast(const float *d_x, int64_t n, int64_t row_base, const void *d_in
         attr_done = true;
     }
     EpsConst eps;
-    eps.rel_c = 1.25f * (9.765625e-4f + 1.1f * d * 5.9604645e-8f + 1.1920929e-7f);
+    eps.rel_c = 1.25f * (9.765625e-4f + 1.1f * d * 5.9604645e-8f);
+    eps.acc_m = 1.25f * 2.1f * d * 5.9604645e-8f;
+    eps.cen = 1.25f * 1.1920929e-7f;
     eps.abs_c = 1.25f * 5.9604645e-8f * sqrtf((float)d);
     eps.chain_o = 1.25f * d * 5.9604645e-8f;
+    // ---- the mean query of this call and its per-row share of every score (skipped on the device when |mq| is small) ----
+    {
+        const IndexLayout Li = index_layout(n, d);
+        const char *ib = reinterpret_cast<const char *>(align_up((uintptr_t)d_index, 256));
+        const int n_part_q = (int)(nq < 1024 ? nq : 1024);
+        ProfScope ps(PC_PLAN, st);
+        hipLaunchKernelGGL(idx_colsum_kernel, dim3((unsigned)n_part_q), dim3(256), 0, st, d_q, nq, d, qpart);
+        hipLaunchKernelGGL(idx_mean_kernel, dim3((unsigned)((d + 255) / 256)), dim3(256), 0, st, qpart, n_part_q, nq, d,
+                           env_int("ANCE_FAST_CENTER", 1) != 0, mq);
+        hipLaunchKernelGGL(query_mean_decide_kernel, dim3(1), dim3(256), 0, st, mq, d, reinterpret_cast<const DedupHeader *>(ib), qstat);
+        (void)hipMemsetAsync(bias, 0, pl.bias_bytes, st);
+        hipLaunchKernelGGL(row_bias_kernel, dim3(4096), dim3(256), 0, st, d_x, d, reinterpret_cast<const DedupHeader *>(ib),
+                           reinterpret_cast<const uint32_t *>(ib + Li.live_off), reinterpret_cast<const float *>(ib + Li.mu_off), mq,
+                           qstat, bias);
+    }
     const int share = env_int("ANCE_FAST_SHARE", 1);
     const int wait_us = env_int("ANCE_FAST_WINDOW_WAIT_US", 200);
     const int prune_at = env_int("ANCE_FAST_PRUNE_AT", 512);
@@ -1156,10 +1284,10 @@ int ip_topk_fast(const float *d_x, int64_t n, int64_t row_base, const void *d_in
         {
             ProfScope ps(PC_PLAN, st);
             hipLaunchKernelGGL(round_rows_kernel, dim3((unsigned)((nqc + 3) / 4 < 8192 ? (nqc + 3) / 4 : 8192)), dim3(256), 0, st,
-                               d_q + (size_t)q0 * d, nqc, d, q2, qn);
+                               d_q + (size_t)q0 * d, nqc, d, mq, q2, qn, qn_o);
         }
         FastParams P;
-        P.q2 = q2; P.x2 = reinterpret_cast<const _Float16 *>(ibase + L.x2_off); P.q32 = d_q + (size_t)q0 * d; P.x32 = d_x; P.qnorm = qn;
+        P.q2 = q2; P.x2 = reinterpret_cast<const _Float16 *>(ibase + L.x2_off); P.q32 = d_q + (size_t)q0 * d; P.x32 = d_x; P.qnorm_c = qn; P.qnorm_o = qn_o; P.qstat = qstat; P.bias = bias;
         P.hdr = H; P.live2row = reinterpret_cast<const uint32_t *>(ibase + L.live_off);
         P.nq = (uint32_t)nqc; P.d = d; P.k = k; P.S = pl.S; P.Ws = pl.Ws;
         P.n_qt = (int)((nqc + FQ - 1) / FQ);
@@ -1177,12 +1305,17 @@ int ip_topk_fast(const float *d_x, int64_t n, int64_t row_base, const void *d_in
         const unsigned blocks = (unsigned)((groups + 7) / 8 * 8) * 32u;
         {
             ProfScope ps(PC_SCAN, st, 2.0 * (double)nqc * (double)n * (double)d);
-            if (stamps) hipLaunchKernelGGL(ip_topk_fast_kernel<true>, dim3(blocks), dim3(F_THREADS), F_LDS_BYTES, st, P);
-            else hipLaunchKernelGGL(ip_topk_fast_kernel<false>, dim3(blocks), dim3(F_THREADS), F_LDS_BYTES, st, P);
+            if (stamps) {
+                hipLaunchKernelGGL((ip_topk_fast_kernel<true, false>), dim3(blocks), dim3(F_THREADS), F_LDS_BYTES, st, P);
+                hipLaunchKernelGGL((ip_topk_fast_kernel<true, true>), dim3(blocks), dim3(F_THREADS), F_LDS_BYTES, st, P);
+            } else {
+                hipLaunchKernelGGL((ip_topk_fast_kernel<false, false>), dim3(blocks), dim3(F_THREADS), F_LDS_BYTES, st, P);
+                hipLaunchKernelGGL((ip_topk_fast_kernel<false, true>), dim3(blocks), dim3(F_THREADS), F_LDS_BYTES, st, P);
+            }
         }
         {
             RescoreParams R;
-            R.q32 = P.q32; R.x32 = d_x; R.qnorm = qn; R.hdr = H; R.live2row = P.live2row; R.cand = cand; R.cnt_g = cnt_g; R.thr_g = thr_g;
+            R.q32 = P.q32; R.x32 = d_x; R.qnorm_c = qn; R.qnorm_o = qn_o; R.qstat = qstat; R.hdr = H; R.live2row = P.live2row; R.cand = cand; R.cnt_g = cnt_g; R.thr_g = thr_g;
             R.part = part; R.nq = P.nq; R.d = d; R.k = k; R.S = pl.S; R.eps = eps;
             ProfScope ps(PC_RESCORE, st);
             hipLaunchKernelGGL(rescore_kernel, dim3((unsigned)(P.n_qt * pl.S * FQ)), dim3(64), rescore_lds_bytes(d), st, R);

@@ -1,12 +1,14 @@
 """The error slack of the two-precision search (ance_amd/csrc/ip_topk_fast.hip) restated and attacked on the CPU.
 
-The fast search filters the corpus with fp16-operand / fp32-accumulate scores s~ = fp16(q) . fp16(x') of the CENTRED rows
-x' = fl32(x - mu) and keeps every row whose s~ is within 2 eps of the k-th best; exactness of the final result needs
-|s~ - (C - q . mu)| <= eps for EVERY (query, row), where C is the canonical fp32 fmaf-chain score of (q, x) and q . mu is
-the (real-number) constant the centring removes from every score of the query.
-eps = rel_c |q| max|x'| + abs_c (|q| + max|x'|) + chain_o |q| max|x| with the three constants below.  This test recomputes
-s~ under several accumulation orders (the MFMA's internal order is not specified) on random and adversarial vectors, with
-and without a large common component, and checks the bound, and that the constants here are the ones compiled into the kernel."""
+The fast search filters the corpus with  s~ = b + fp16(dq) . fp16(x')  (fp32 accumulation starting from b), where
+x' = fl32(x - mu) is the row centred on the shard mean, dq = fl32(q - mq) the query centred on the mean query of the call
+and b = fl32(mq . x') that mean query's share of the row's score; it keeps every row whose s~ is within 2 eps of the k-th
+best.  Exactness of the final result needs |s~ - (C - q . mu)| <= eps for EVERY (query, row), where C is the canonical fp32
+fmaf-chain score of (q, x) and q . mu the (real-number) constant the centring removes from every score of the query.
+eps = rel_c |dq| X' + acc_m |mq| X' + cen |q| X' + abs_c (|dq| + X') + chain_o |q| X   (X' = max |x'|, X = max |x|).
+This test recomputes s~ under several accumulation orders (the MFMA's internal order is not specified) on random and
+adversarial vectors, with and without large common components, and checks the bound, and that the constants here are the
+ones compiled into the kernel."""
 import os
 import re
 
@@ -18,18 +20,21 @@ SRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 
 
 def slack(d):
     u = np.float32(5.9604645e-8)
-    rel = np.float32(1.25) * (np.float32(9.765625e-4) + np.float32(1.1) * np.float32(d) * u + np.float32(1.1920929e-7))
-    ab = np.float32(1.25) * u * np.float32(np.sqrt(np.float32(d)))
-    ch = np.float32(1.25) * np.float32(d) * u
-    return float(rel), float(ab), float(ch)
+    f = np.float32(1.25)
+    return dict(rel_c=float(f * (np.float32(9.765625e-4) + np.float32(1.1) * np.float32(d) * u)),
+                acc_m=float(f * np.float32(2.1) * np.float32(d) * u), cen=float(f * np.float32(1.1920929e-7)),
+                abs_c=float(f * u * np.float32(np.sqrt(np.float32(d)))), chain_o=float(f * np.float32(d) * u))
 
 
 def test_constants_are_the_kernels():
     src = open(SRC).read()
-    assert re.search(r"eps\.rel_c = 1\.25f \* \(9\.765625e-4f \+ 1\.1f \* d \* 5\.9604645e-8f \+ 1\.1920929e-7f\);", src)
+    assert re.search(r"eps\.rel_c = 1\.25f \* \(9\.765625e-4f \+ 1\.1f \* d \* 5\.9604645e-8f\);", src)
+    assert re.search(r"eps\.acc_m = 1\.25f \* 2\.1f \* d \* 5\.9604645e-8f;", src)
+    assert re.search(r"eps\.cen = 1\.25f \* 1\.1920929e-7f;", src)
     assert re.search(r"eps\.abs_c = 1\.25f \* 5\.9604645e-8f \* sqrtf\(\(float\)d\);", src)
     assert re.search(r"eps\.chain_o = 1\.25f \* d \* 5\.9604645e-8f;", src)
-    assert re.search(r"2\.0f \* \(E\.rel_c \* qn \* xc \+ E\.abs_c \* \(qn \+ xc\) \+ E\.chain_o \* qn \* xo\)", src)
+    assert re.search(r"2\.0f \* \(E\.rel_c \* qc \* xc \+ E\.acc_m \* qs->mq_norm \* xc \+ E\.cen \* qo \* xc \+ E\.abs_c \* \(qc \+ xc\) \+ "
+                     r"E\.chain_o \* qo \* xo\)", src)
     assert 9.765625e-4 == 2.0 ** -10 and abs(5.9604645e-8 - 2.0 ** -24) < 1e-15 and abs(1.1920929e-7 - 2.0 ** -23) < 1e-15
 
 
@@ -41,28 +46,29 @@ def chain(q, x):
     return float(s)
 
 
-def approx_scores(q, x):
-    """s~ under several fp32 accumulation orders of the fp16-rounded operands."""
+def approx_scores(q, x, b0=0.0):
+    """s~ = b0 + sum of the fp16-rounded operands' products, under several fp32 accumulation orders."""
     qh = q.astype(np.float16).astype(np.float32)
     xh = x.astype(np.float16).astype(np.float32)
     p = qh * xh  # exact in fp32: 11-bit x 11-bit significands
+    b0 = np.float32(b0)
     out = []
-    s = np.float32(0)
+    s = b0
     for v in p:
         s = np.float32(s + v)
-    out.append(float(s))                                   # sequential
+    out.append(float(s))                                   # sequential, bias first (what the accumulator init does)
     s = np.float32(0)
     for v in p[::-1]:
         s = np.float32(s + v)
-    out.append(float(s))                                   # reversed
+    out.append(float(np.float32(s + b0)))                  # reversed, bias last
     t = p.copy()
     while len(t) > 1:                                      # pairwise tree
         if len(t) % 2:
             t = np.append(t, np.float32(0))
         t = (t[0::2] + t[1::2]).astype(np.float32)
-    out.append(float(t[0]))
-    blk = p.reshape(-1, 16).sum(axis=1, dtype=np.float32)  # 16-wide blocks (one MFMA k-step), then sequential
-    s = np.float32(0)
+    out.append(float(np.float32(t[0] + b0)))
+    blk = p.reshape(-1, 16).sum(axis=1, dtype=np.float32)  # 16-wide blocks (one MFMA k-step), then sequential from the bias
+    s = b0
     for v in blk:
         s = np.float32(s + v)
     out.append(float(s))
@@ -82,16 +88,19 @@ def vectors(rng, d):
     yield np.full(d, u, np.float32), np.full(d, u, np.float32)
 
 
-def check(q, x, mu, d, worst):
-    rel, ab, ch = slack(d)
-    xc = (x - mu).astype(np.float32)  # fl32(x - mu), what the image rounds to fp16
-    qn = float(np.linalg.norm(q.astype(np.float64)))
-    eps = rel * qn * float(np.linalg.norm(xc.astype(np.float64))) + ab * (qn + float(np.linalg.norm(xc.astype(np.float64)))) \
-        + ch * qn * float(np.linalg.norm(x.astype(np.float64)))
+def check(q, x, mu, mq, d, worst):
+    E = slack(d)
+    xc = (x - mu).astype(np.float32)   # fl32(x - mu), what the image rounds to fp16
+    dq = (q - mq).astype(np.float32)   # fl32(q - mq), what the query chunk rounds to fp16
+    n64 = lambda v: float(np.linalg.norm(v.astype(np.float64)))
+    eps = E["rel_c"] * n64(dq) * n64(xc) + E["acc_m"] * n64(mq) * n64(xc) + E["cen"] * n64(q) * n64(xc) \
+        + E["abs_c"] * (n64(dq) + n64(xc)) + E["chain_o"] * n64(q) * n64(x)
     target = chain(q, x) - float(np.dot(q.astype(np.float64), mu.astype(np.float64)))
-    for st in approx_scores(q, xc):
-        assert abs(st - target) <= eps, (d, st, target, eps)
-        worst[0] = max(worst[0], abs(st - target) / eps)
+    biases = [chain(mq, xc), float(np.float32(np.dot(mq.astype(np.float64), xc.astype(np.float64))))]  # fp32 chain / correctly rounded
+    for b0 in biases:
+        for st in approx_scores(dq, xc, b0):
+            assert abs(st - target) <= eps, (d, st, target, eps)
+            worst[0] = max(worst[0], abs(st - target) / eps)
 
 
 @pytest.mark.parametrize("d", [128, 768, 1024, 2048])
@@ -101,24 +110,27 @@ def test_bound_holds(d):
     zero = np.zeros(d, np.float32)
     for rep in range(5):
         for q, x in vectors(rng, d):
-            check(q, x, zero, d, worst)  # no centring (mu = 0): the bound of round 1 plus the chain term
+            check(q, x, zero, zero, d, worst)  # no centring at all (mu = mq = 0)
     assert worst[0] < 0.95  # the slack is not razor-thin on any of these
 
 
 @pytest.mark.parametrize("d", [128, 768])
-def test_bound_holds_with_a_large_common_component(d):
-    """rows = c + small deviation (cosine ~0.99 between rows, like the embeddings of one encoder): the centred image makes
-    |x'| ~ 10x smaller than |x| and the bound shrinks with it -- and still holds, for exact and for sloppy means."""
+def test_bound_holds_with_large_common_components(d):
+    """rows = c + small deviation, queries = c' + small deviation (cosine ~0.99 inside each set, like the embeddings of one
+    encoder / of DPR's two towers): the centred operands are ~10x smaller than the vectors and the bound shrinks with them
+    -- and still holds, for exact and for sloppy means, with and without the query mean."""
     rng = np.random.default_rng(100 + d)
     worst = [0.0]
-    c = (rng.standard_normal(d) * 1.0).astype(np.float32)
-    c = (c / np.linalg.norm(c) * np.sqrt(d)).astype(np.float32)
-    for rep in range(12):
+    unit = lambda v: (v / np.linalg.norm(v) * np.sqrt(d)).astype(np.float32)
+    c = unit(rng.standard_normal(d))
+    c2 = unit(c + 0.5 * unit(rng.standard_normal(d)))
+    zero = np.zeros(d, np.float32)
+    for rep in range(10):
         x = (c + 0.12 * rng.standard_normal(d)).astype(np.float32)
-        q = (c + 0.12 * rng.standard_normal(d)).astype(np.float32)
-        for mu in (c, (c * np.float32(0.97)).astype(np.float32), (c + 0.05 * rng.standard_normal(d)).astype(np.float32)):
-            check(q, x, mu, d, worst)
-        check((-q).astype(np.float32), x, c, d, worst)
+        for cq in (c, c2):
+            q = (cq + 0.12 * rng.standard_normal(d)).astype(np.float32)
+            for mu in (c, (c * np.float32(0.97)).astype(np.float32), (c + 0.05 * rng.standard_normal(d)).astype(np.float32)):
+                for mq in (zero, cq, (cq + 0.05 * rng.standard_normal(d)).astype(np.float32)):
+                    check(q, x, mu, mq, d, worst)
+            check((-q).astype(np.float32), x, c, (-cq).astype(np.float32), d, worst)
     assert worst[0] < 0.95
-
-

@@ -542,3 +542,18 @@ def test_whole_chunk_redo_with_a_short_last_chunk(monkeypatch):
     pick = np.concatenate([np.arange(0, 40), np.arange(4090, 4130), np.arange(6940, 6980)])
     Do, Io = search_ref.flat_ip_topk_chain(x, q[pick], 100)
     assert np.array_equal(I[pick], Io) and np.array_equal(D[pick], Do)
+
+
+def test_two_towers_with_different_common_components():
+    """DPR-like: queries share one large component, passages another (two encoders): the mean QUERY is taken out of the fp16
+    operand too and comes back as a per-row bias; bit-exact results all the same."""
+    rng = np.random.default_rng(53)
+    x, c = _encoder_like(rng, 70000)
+    c2 = rng.standard_normal(768).astype(np.float32)
+    c2 = (0.8 * c + 0.6 * c2 / np.linalg.norm(c2) * np.sqrt(768.0)).astype(np.float32)
+    q = (c2[None, :] + 0.12 * rng.standard_normal((700, 768))).astype(np.float32)
+    _check_exact("two_towers", x, q, 100)
+    # a handful of queries only (the mean query of a small call), and queries with no common component at all
+    _check_exact("two_towers_few", x, q[:3], 200)
+    from oracle import synth
+    _check_exact("common_rows_ln_queries", x, synth.ln_rows(rng, 90), 50)
