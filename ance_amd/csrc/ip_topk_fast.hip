@@ -494,11 +494,8 @@ struct FastParams {
     FastCtl *ctl;
     int *ovf_flag;  // [nq] 0 / 1
     int *ovf_list;  // [OVF_CAP]
-    unsigned int *grp_ctr;  // [groups] tiles finished by the workgroups of an XCD group (tile_sync)
     int prune_at;           // first scheduled prune once every list has this many rows (<= F_C - FP)
     int prune_growth;       // percent: the tile count between scheduled prunes grows by this factor (150 = 1.5x)
-    int tile_sync;          // keep the 32 workgroups of an XCD group on the same corpus tile step (bounded wait)
-    unsigned int tile_wait_ticks;
     int dbg;                     // STAMPS kernel only, timing experiments (results WRONG): 1 = no insertions after window 4,
                                  // 2 = no filter at all after window 4, 3 = as 2 and no prune check either
     unsigned long long *stamps;  // measurement: [workgroup][8] accumulated 100 MHz ticks (STAMPS kernel only)
@@ -672,20 +669,6 @@ __global__ void __launch_bounds__(F_THREADS, 2) ip_topk_fast_kernel(const FastPa
     };
     int n_done = 0, next_sched = max(1, (P.prune_at + FP - 1) / FP);
 
-    // tiles of this split / of split 0 (the longest sequence) over the whole scan: the tile-step counter of the XCD
-    // group must see the same number of arrivals from every member
-    unsigned T_mine = 0, T_first = 0, n_in_grp = 0, step = 0;
-    if (P.tile_sync) {
-        const int last0 = (n_win - 1) * W;
-        auto tiles_of = [&](int sp) {
-            const int rest = n_tiles - last0 - sp * P.Ws;
-            return (unsigned)((n_win - 1) * P.Ws + (rest < 0 ? 0 : (rest < P.Ws ? rest : P.Ws)));
-        };
-        T_mine = tiles_of(split);
-        T_first = tiles_of(0);
-        const int q_in_grp = min(gq, P.n_qt - grp * gq);
-        n_in_grp = (unsigned)(q_in_grp * P.S);
-    }
     unsigned long long t_last = 0, a_main = 0, a_filter = 0, a_prune = 0, a_sync = 0, a_end = 0, a_pro = 0;
     if constexpr (STAMPS) t_last = wall_clock64();
 
@@ -861,25 +844,6 @@ __global__ void __launch_bounds__(F_THREADS, 2) ip_topk_fast_kernel(const FastPa
             }
         }
         STAMP(a_prune)
-        // ---- tile step of the XCD group: the 32 workgroups that share this XCD's L2 stay on the same tile step, so
-        // that a K-slice of a query / corpus tile is still in the L2 when its other readers ask for it ---------------
-        if (P.tile_sync) {
-            if (tid == 0) {
-                __hip_atomic_fetch_add(&P.grp_ctr[grp], have_n ? 1u : 1u + (T_first - T_mine), __ATOMIC_RELAXED,
-                                       __HIP_MEMORY_SCOPE_AGENT);
-                if (have_n) {
-                    const unsigned target = (step + 1) * n_in_grp;
-                    const unsigned long long t_in = wall_clock64();
-                    while (__hip_atomic_load(&P.grp_ctr[grp], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-                        __builtin_amdgcn_s_sleep(8);
-                        if (wall_clock64() - t_in > P.tile_wait_ticks) break;
-                    }
-                }
-            }
-            ++step;
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-        }
         // ---- window boundary: wait (bounded) for the other workgroups, adopt their thresholds ----------
         if (winn != win && winn < n_win) {  // block-uniform
             if (tid == 0) {
@@ -1112,7 +1076,7 @@ bool make_fast_plan(int64_t n, int64_t nq, int d, int k, FastPlan *pl) {
     pl->part_bytes = align_up((size_t)pl->qc * S * k * sizeof(u64), 256);
     pl->thr_bytes = align_up((size_t)qct * S * FQ * sizeof(float) + (size_t)pl->qc * sizeof(int), 256);  // thr_g + fb_slot (0xFF fill)
     pl->cnt_bytes = align_up((size_t)qct * S * FQ * sizeof(int), 256);
-    pl->flag_bytes = align_up(256 + (size_t)pl->qc * sizeof(int) + OVF_CAP * sizeof(int) + 1024 * sizeof(int), 256);  // ctl + ovf_flag + ovf_list + grp_ctr (0 fill)
+    pl->flag_bytes = align_up(256 + (size_t)pl->qc * sizeof(int) + OVF_CAP * sizeof(int), 256);  // ctl + ovf_flag + ovf_list (0 fill)
     pl->qfb_bytes = align_up((size_t)OVF_CAP * d * sizeof(float), 256);
     pl->fbk_bytes = align_up((size_t)OVF_CAP * k * sizeof(u64), 256);
     const int64_t nqc = nq < pl->qc ? nq : pl->qc;
@@ -1274,8 +1238,6 @@ int ip_topk_fast(const float *d_x, int64_t n, int64_t row_base, const void *d_in
     const int prune_at = env_int("ANCE_FAST_PRUNE_AT", 512);
     int prune_growth = env_int("ANCE_FAST_PRUNE_GROWTH", 150);
     if (prune_growth < 105) prune_growth = 105;
-    const int tile_sync = env_int("ANCE_FAST_TILE_SYNC", 0);
-    const int tile_wait_us = env_int("ANCE_FAST_TILE_WAIT_US", 30);
     unsigned long long *stamps = g_fast_stamps;  // measurement hook (ance_debug_search_stamps)
     for (int64_t q0 = 0; q0 < nq; q0 += pl.qc) {
         const int64_t nqc = (nq - q0) < pl.qc ? (nq - q0) : pl.qc;
@@ -1294,11 +1256,9 @@ int ip_topk_fast(const float *d_x, int64_t n, int64_t row_base, const void *d_in
         P.share = share && pl.S > 1; P.wait_ticks = (unsigned)(wait_us > 0 ? wait_us * 100 : 0);
         P.eps = eps; P.cand = cand; P.part = part; P.thr_g = thr_g; P.ctl = ctl;
         P.ovf_flag = ovf_flag; P.ovf_list = ovf_list; P.cnt_g = cnt_g;
-        P.grp_ctr = reinterpret_cast<unsigned int *>(ovf_list + OVF_CAP);
         P.prune_at = prune_at > k + 64 ? prune_at : k + 64;
         if (P.prune_at > F_C - FP) P.prune_at = F_C - FP;
         P.prune_growth = prune_growth;
-        P.tile_sync = tile_sync; P.tile_wait_ticks = (unsigned)(tile_wait_us > 0 ? tile_wait_us * 100 : 0);
         P.stamps = stamps; P.dbg = env_int("ANCE_FAST_DEBUG", 0);
         const int gq = 32 / pl.S;
         const int groups = (P.n_qt + gq - 1) / gq;

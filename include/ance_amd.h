@@ -223,10 +223,8 @@ int ance_debug_gemm(int ablate, int epi, const void *d_a_f16, const void *d_b_f1
 /*
  * Measurement hook of the two-precision search: while d_stamps != NULL, the filter kernel runs as its instrumented
  * build and every workgroup of a launch chunk leaves uint64[8] at d_stamps + 8 * blockIdx: ticks of the 100 MHz
- * counter spent in {prologue, fp16 main loop, filter, prune, waits (tile step + window), block-end exact re-scoring},
+ * counter spent in {prologue, fp16 main loop, filter, prune, window waits, hand-over to the re-scoring kernel},
  * then (query tile << 32 | split) and the XCC id it ran on.  The buffer needs 8 * 8 * 2048 bytes.  NULL switches it off.
- * Also read at every call (tuning / A-B): ANCE_FAST_TILE_SYNC=1 keeps the workgroups of an XCD on the same corpus
- * tile step (bounded wait ANCE_FAST_TILE_WAIT_US, default 30).
  */
 void ance_debug_search_stamps(void *d_stamps);
 

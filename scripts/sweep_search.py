@@ -34,9 +34,9 @@ def main():
     idx.add(x)
     # every configuration: ANCE_FAST_* environment of the library (read at every call), short names below
     names_ = dict(S="ANCE_FAST_SPLITS", W="ANCE_FAST_WINDOW_TILES", share="ANCE_FAST_SHARE", wait="ANCE_FAST_WINDOW_WAIT_US",
-                  tsync="ANCE_FAST_TILE_SYNC", twait="ANCE_FAST_TILE_WAIT_US", prune="ANCE_FAST_PRUNE_AT", dbg="ANCE_FAST_DEBUG", grow="ANCE_FAST_PRUNE_GROWTH")
-    base = dict(S=2, W=256, share=1, wait=200, tsync=0, twait=30, prune=512, dbg=0, grow=150)
-    configs = ["", "grow=200", "grow=125", "tsync=1,twait=10", "tsync=1,twait=30", "wait=50", "W=512", "S=4"]
+                  prune="ANCE_FAST_PRUNE_AT", dbg="ANCE_FAST_DEBUG", grow="ANCE_FAST_PRUNE_GROWTH")
+    base = dict(S=2, W=256, share=1, wait=200, prune=512, dbg=0, grow=150)
+    configs = ["", "grow=200", "grow=125", "wait=50", "W=512", "W=0,wait=0", "S=4", "share=0"]
     if a.configs:
         configs = a.configs.split(";")
     from ance_amd import _lib
