@@ -436,11 +436,15 @@ def test_dedup_at_scale_is_not_slower():
         idx = FlatIPIndex(768)
         idx.add(xx)
         idx.search(q[:256], k)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        D, I = idx.search(q, k)
-        torch.cuda.synchronize()
-        return time.perf_counter() - t0, D.cpu().numpy(), I.cpu().numpy()
+        best = None
+        for _ in range(3):  # best of three: the assertion below is about the kernel, not about a noisy neighbour
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            D, I = idx.search(q, k)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        return best, D.cpu().numpy(), I.cpu().numpy()
 
     t_distinct, _, _ = timed(x)
     v0 = x[123].clone()
@@ -503,11 +507,15 @@ def test_common_component_stays_on_the_fast_path():
         idx = FlatIPIndex(768)
         idx.add(x)
         idx.search(q[:256], k)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        D, I = idx.search(q, k)
-        torch.cuda.synchronize()
-        return time.perf_counter() - t0, D, I
+        best = None
+        for _ in range(3):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            D, I = idx.search(q, k)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        return best, D, I
 
     xl = torch.nn.functional.layer_norm(torch.randn((n, 768), generator=g, device="cuda"), (768,))
     ql = torch.nn.functional.layer_norm(torch.randn((nq, 768), generator=g, device="cuda"), (768,))
