@@ -3,26 +3,29 @@
 // gfx950 has no reduced-precision path for fp32 inputs (no xf32), and the exact fp32 MFMA runs at
 // 1/16 of the fp16 rate.  This kernel gets the fp16 rate WITHOUT giving up bit-exact results:
 //
-//   1. the corpus shard is turned ONCE into a search image (ance_ip_index_build): rows rounded to fp16
-//      (xh = fp16(x)), the maximum row norm, and -- when a sample of the shard shows heavy duplicate
+//   1. the corpus shard is turned ONCE into a search image (ance_ip_index_build): the shard's mean row mu, every row as
+//      fp16(x - mu), the maximum norms of x - mu and of x, and -- when a sample of the shard shows heavy duplicate
 //      classes (the all-pad MaxP chunks of model/models.py:165-199 are millions of bit-identical rows)
 //      -- every class collapsed to its smallest row id; the image is compacted, `live2row` maps image
 //      rows back to shard rows and the first ids of every class are kept for the expansion in step 6;
-//   2. an approximate score  s~ = qh . xh  is a plain fp16 GEMM on the 256 x 256 x 64 direct-to-LDS
-//      main loop of pipe256.h (queries are the "m" side, so a lane owns a query);
-//   3. with eps a rigorous bound on |s~ - s| (below) and t~ the k-th best APPROXIMATE score seen so
+//   2. an approximate score  s~ = b + fp16(q - mq) . fp16(x - mu)  (b, mq: "Error bound" below) is an fp16 GEMM on the
+//      256 x 256 x 64 direct-to-LDS main loop of pipe256.h (queries are the "m" side, so a lane owns a query), streamed
+//      across the corpus tiles of a workgroup;
+//   3. with eps a rigorous bound on the error of s~ (below) and t~ the k-th best APPROXIMATE score seen so
 //      far, a row with s~ < t~ - 2 eps can never be in the exact top-k (k rows have s >= t~ - eps
 //      > its s), so the per-query buffers keep exactly the rows with s~ >= t~ - 2 eps: about
 //      k + 2 eps * density rows (~270 for k = 200 on LayerNorm-distributed rows).  The bound holds for
 //      t~ taken over ANY subset of rows, so the workgroups that scan different corpus splits for the same
 //      queries exchange their thresholds through global memory (stale values are merely weaker bounds);
 //   4. the corpus is scanned in WINDOWS of ~100 MB that every workgroup of the launch finishes before any
-//      moves on (a counter with a bounded spin: a scheduling hint, no data depends on it), so the 256 MB
-//      Infinity Cache serves all but the first reader of a corpus tile;
-//   5. when a block has scanned its share, the rows within 2 eps of the final k-th best approximate score
-//      are re-scored with the exact fp32 fmaf chain over k ascending (the contract of
-//      oracle/ip_topk_ref.c) -- one query per wave at a time, its fp32 row broadcast from LDS, 64 rows in
-//      flight -- and the exact top-k under (score desc, row asc) is selected from exact keys;
+//      moves on (a counter with a bounded spin: a scheduling hint, no data depends on it), and every list of every
+//      workgroup is pruned at the same geometrically spaced tile counts: the workgroups stay within microseconds of each
+//      other, the 16 of an XCD that scan the same corpus split find its tiles in their L2 (hit rate 15 % -> 58 %) and the
+//      256 MB Infinity Cache serves the other XCDs;
+//   5. when the scan is over, rescore_kernel (one wave per list) re-scores the rows within 2 eps of the final k-th best
+//      approximate score with the exact fp32 fmaf chain over k ascending (the contract of oracle/ip_topk_ref.c) -- 64 rows
+//      per round, one per lane, their fp32 data staged through LDS by coalesced 1 KiB LDS-DMAs -- and selects the exact
+//      top-k under (score desc, row asc) from exact keys;
 //   6. topk_finalize merges the splits and, for every duplicate class whose representative survived, adds
 //      the class members (same exact score, ascending ids) before the final sort.
 //   A query whose buffer cannot be pruned below its capacity (more than ~1,800 rows inside one 2 eps
