@@ -44,7 +44,22 @@ __device__ __forceinline__ f32x4 gelu_erf256(f32x4 x) {
     return out;
 }
 
-template <int EPI>
+// WAVE_SYNC: the slabs are wave-private and, once the main loop has returned, no wave reads the stage buffers any more
+// (pipe256.h: the last barrier every wave passes comes after the last LDS read of both wave groups), so the write ->
+// read-back -> next-pass-write ordering inside a slab is a matter of ONE wave: LDS operations of a wave execute in order,
+// and a wavefront-scope fence keeps the compiler from moving a lane's read above another lane's write.  Without it every
+// pass costs two workgroup barriers that make all eight waves wait for the slowest one.
+template <bool WAVE_SYNC>
+__device__ __forceinline__ void epi_sync() {
+    if constexpr (WAVE_SYNC) {
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    } else {
+        __syncthreads();
+    }
+}
+
+template <int EPI, bool WAVE_SYNC = false>
 __device__ __forceinline__ void gemm256_epilogue(const GemmArgs &G, f32x16 (&acc)[2][4], float *smem_f, int m0, int n0,
                                                  int w, int l) {
     _Float16 *smem = reinterpret_cast<_Float16 *>(smem_f);
@@ -65,7 +80,7 @@ __device__ __forceinline__ void gemm256_epilogue(const GemmArgs &G, f32x16 (&acc
         const int col = tok_ok ? G.col_map[ntok] : 0;
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
-            __syncthreads();
+            epi_sync<WAVE_SYNC>();
 #pragma unroll
             for (int yy = 0; yy < 2; ++yy) {
                 const float bias = G.bias[mw0 + (2 * p + yy) * 32 + i];
@@ -79,7 +94,7 @@ __device__ __forceinline__ void gemm256_epilogue(const GemmArgs &G, f32x16 (&acc
                                   (_Float16)(a[4 * rq + 2] + bias), (_Float16)(a[4 * rq + 3] + bias)};
                     }
             }
-            __syncthreads();
+            epi_sync<WAVE_SYNC>();
             if (tok_ok) {
                 _Float16 *obase = G.out16 + (size_t)(mw0 + p * 64) * G.ldc + col;
 #pragma unroll 8
@@ -117,7 +132,7 @@ __device__ __forceinline__ void gemm256_epilogue(const GemmArgs &G, f32x16 (&acc
 #pragma unroll
                 for (int it = 0; it < 8; ++it) res[it] = ln_apply4(res[it], mean[it], rstd[it], lng, lnb);
             }
-            __syncthreads();
+            epi_sync<WAVE_SYNC>();
 #pragma unroll
             for (int x = 0; x < 2; ++x)
 #pragma unroll
@@ -126,7 +141,7 @@ __device__ __forceinline__ void gemm256_epilogue(const GemmArgs &G, f32x16 (&acc
                     *reinterpret_cast<f32x4 *>(slab + i * LS + x * 32 + 8 * rq + 4 * g) =
                         f32x4{a[4 * rq], a[4 * rq + 1], a[4 * rq + 2], a[4 * rq + 3]};
                 }
-            __syncthreads();
+            epi_sync<WAVE_SYNC>();
             // read back: 16 lanes cover one row (64 floats), 4 rows per instruction, 8 instructions
 #pragma unroll
             for (int it = 0; it < 8; ++it) {
@@ -141,7 +156,7 @@ __device__ __forceinline__ void gemm256_epilogue(const GemmArgs &G, f32x16 (&acc
         constexpr int LS = 72;
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
-            __syncthreads();
+            epi_sync<WAVE_SYNC>();
 #pragma unroll
             for (int yy = 0; yy < 2; ++yy)
 #pragma unroll
@@ -161,7 +176,7 @@ __device__ __forceinline__ void gemm256_epilogue(const GemmArgs &G, f32x16 (&acc
                         const f16x4 v = f16x4{(_Float16)t[0], (_Float16)t[1], (_Float16)t[2], (_Float16)t[3]};
                         *reinterpret_cast<f16x4 *>(slab + (yy * 32 + i) * LS + nl) = v;
                     }
-            __syncthreads();
+            epi_sync<WAVE_SYNC>();
             // read back: 8 lanes cover one row (64 halves = 128 B), 8 rows per instruction
             const int c8 = l & 7;
 #pragma unroll

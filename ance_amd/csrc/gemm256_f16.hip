@@ -29,6 +29,7 @@
 #include "gemm_f16.h"
 #include "gemm256_epilogue.h"
 #include "pipe256.h"
+#include <stdlib.h>
 #include <string.h>
 
 namespace ance {
@@ -135,6 +136,49 @@ __device__ __forceinline__ void two_phase_loop(const GemmArgs &G, f32x16 (&acc)[
 
 }
 
+// Product kernel, second form (ANCE_GEMM_DESC=0 selects the first one below for A/B): operands through buffer
+// descriptors (PipeSrcDesc), epilogue passes ordered inside the wave instead of by workgroup barriers.
+template <int EPI>
+__global__ void __launch_bounds__(G256_THREADS, 2) gemm256_f16_desc_kernel(const GemmArgs G) {
+    extern __shared__ __attribute__((aligned(16))) float smem_f[];
+    _Float16 *smem = reinterpret_cast<_Float16 *>(smem_f);
+    const int NT = G.N / TN, MT = G.M / TM;
+    const int b = blockIdx.x, xcd = b & 7, jx = b >> 3;  // XCD-aware tile order: see gemm256_f16_kernel
+    int mt, nt;
+    if (MT >= NT) {
+        mt = (jx / NT) * 8 + xcd;
+        nt = jx % NT;
+    } else {
+        nt = (jx / MT) * 8 + xcd;
+        mt = jx % MT;
+    }
+    if (mt >= MT || nt >= NT) return;
+    const int m0 = mt * TM, n0 = nt * TN;
+    const int tid = threadIdx.x;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l = tid & 63;
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 4; ++y) acc[x][y] = f32x16{0};
+    Pipe256T<PipeSrcDesc, false, true, true> P;
+    P.init(smem, w, l);
+    // descriptors of this tile's 256 rows of each operand (bases are wave-uniform: kernel arguments and blockIdx)
+    P.S.ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16 *>(G.A + (size_t)m0 * G.lda), 0, (int)(256u * (uint32_t)G.lda * 2u), 0x00020000);
+    P.S.rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16 *>(G.B + (size_t)n0 * G.ldb), 0, (int)(256u * (uint32_t)G.ldb * 2u), 0x00020000);
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int r = pipe_stage_row(w, l, j), ch = pipe_stage_chunk(r, l);
+            P.S.voff[h][j] = (uint32_t)(pipe_a_tile_row(h, r) * G.lda + ch) * 2u;
+            P.S.voff[2 + h][j] = (uint32_t)(pipe_b_tile_row(h, r) * G.ldb + ch) * 2u;
+        }
+    P.run(G.K / TK, acc);
+    gemm256_epilogue<EPI, true>(G, acc, smem_f, m0, n0, w, l);
+}
+
 template <int EPI, bool ABLATE>
 __global__ void __launch_bounds__(G256_THREADS, 2) gemm256_f16_kernel(const GemmArgs G) {
     extern __shared__ __attribute__((aligned(16))) float smem_f[];
@@ -214,19 +258,26 @@ int launch256(int epi, const GemmArgs &G, hipStream_t st) {
     const int MT = G.M / TM, NT = G.N / TN;
     const unsigned blocks = MT >= NT ? (unsigned)((MT + 7) / 8 * 8) * (unsigned)NT : (unsigned)((NT + 7) / 8 * 8) * (unsigned)MT;
     void (*k)(const GemmArgs) = nullptr;
+    static int use_desc = -1;
+    if (use_desc < 0) {
+        const char *e = getenv("ANCE_GEMM_DESC");
+        use_desc = (e && atoi(e) == 0) ? 0 : 1;
+    }
+    const bool desc = !ABLATE && use_desc;
     switch (epi) {
-        case EPI_QK: k = gemm256_f16_kernel<EPI_QK, ABLATE>; break;
-        case EPI_GELU: k = gemm256_f16_kernel<EPI_GELU, ABLATE>; break;
-        case EPI_RES32: k = gemm256_f16_kernel<EPI_RES32, ABLATE>; break;
-        case EPI_VT: k = gemm256_f16_kernel<EPI_VT, ABLATE>; break;
+        case EPI_QK: k = desc ? gemm256_f16_desc_kernel<EPI_QK> : gemm256_f16_kernel<EPI_QK, ABLATE>; break;
+        case EPI_GELU: k = desc ? gemm256_f16_desc_kernel<EPI_GELU> : gemm256_f16_kernel<EPI_GELU, ABLATE>; break;
+        case EPI_RES32: k = desc ? gemm256_f16_desc_kernel<EPI_RES32> : gemm256_f16_kernel<EPI_RES32, ABLATE>; break;
+        case EPI_VT: k = desc ? gemm256_f16_desc_kernel<EPI_VT> : gemm256_f16_kernel<EPI_VT, ABLATE>; break;
         default: set_last_error("gemm256: bad epilogue"); return ANCE_E_INVALID;
     }
-    static bool attr_done[4] = {false, false, false, false};  // per template instance
-    if (!attr_done[epi]) {
+    static bool attr_done[8] = {false, false, false, false, false, false, false, false};  // per template instance
+    const int ai = epi + (desc ? 4 : 0);
+    if (!attr_done[ai]) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)G256_LDS_BYTES) != hipSuccess)
             return check_launch("gemm256 attr");
-        attr_done[epi] = true;
+        attr_done[ai] = true;
     }
     hipLaunchKernelGGL(k, dim3(blocks), dim3(G256_THREADS), G256_LDS_BYTES, st, G);
     return ANCE_OK;

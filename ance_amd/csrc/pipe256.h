@@ -76,6 +76,18 @@ struct PipeSrcFixed {
     }
 };
 
+// Source policy of a plain GEMM through buffer descriptors: one descriptor per operand matrix (wave-uniform SGPRs), one
+// 32-bit per-lane byte offset per staged piece that never changes, the K offset in an SGPR -- no 64-bit address
+// arithmetic next to the MFMAs and 8 address VGPRs instead of 16.  Needs matrices below 4 GiB.
+struct PipeSrcDesc {
+    __amdgpu_buffer_rsrc_t ra, rb;
+    uint32_t voff[4][2];  // [A0 A1 B0 B1][piece]
+    template <int TYPE, int J>
+    __device__ __forceinline__ void issue(int t, pipe_lds_t *dst) const {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(TYPE < 2 ? ra : rb, dst, 16, voff[TYPE][J], t * 128, 0, 0);
+    }
+};
+
 // SRC provides  template <int TYPE, int J> void issue(int t, pipe_lds_t *dst)  : the LDS-DMA (16 bytes per lane, 1 KiB per
 // wave, lane-linear at dst) of piece J of half-tile TYPE (0 A-half0, 1 A-half1, 2 B-half0, 3 B-half1) of K-tile t.
 // DBG compiles measurement ablations in (dbg bit 1: no MFMA, bit 3: no staging); product code uses DBG = false.
