@@ -397,7 +397,7 @@ def main():
             ach = prof[dom]["work"] / (prof[dom]["ms"] * 1e-3) / 1e12 if prof[dom]["ms"] > 0 else None
             all_gemm_ms = sum(prof[c]["ms"] for c in gemm_cats)
             all_gemm_work = sum(prof[c]["work"] for c in gemm_cats)
-            out["roofline"] = {"bound": "mfma", "kernel": "gemm256_f16_kernel (%s)" % dom, "achieved": ach, "peak": PEAK_F16_TF,
+            out["roofline"] = {"bound": "mfma", "kernel": "gemm256_f16_desc_kernel (%s)" % dom, "achieved": ach, "peak": PEAK_F16_TF,
                                "unit": "TFLOP/s", "frac": (ach / PEAK_F16_TF) if ach else None, "traffic": pmc_traffic("encode", dom),
                                "timing": "HIP events on the launch stream, single-stream pass of the same %d steps "
                                          "(%.1f ms/step isolated vs %.1f ms/step overlapped)" % (a.steps, 1e3 * dt_iso / a.steps, 1e3 * dt / a.steps),

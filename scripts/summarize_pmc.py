@@ -96,8 +96,8 @@ if len(sys.argv) > 2:
         return (sum(dur) / len(dur), len(dur)) if dur else (None, 0)
 
     out = {}
-    for leg, cat, needle in (("encode", "gemm_ffn1", "gemm256_f16_kernel<1"), ("encode", "gemm_qk", "gemm256_f16_kernel<0"),
-                             ("encode", "gemm_res32", "gemm256_f16_kernel<2"), ("encode", "gemm_vt", "gemm256_f16_kernel<3"),
+    for leg, cat, needle in (("encode", "gemm_ffn1", "gemm256_f16_desc_kernel<1"), ("encode", "gemm_qk", "gemm256_f16_desc_kernel<0"),
+                             ("encode", "gemm_res32", "gemm256_f16_desc_kernel<2"), ("encode", "gemm_vt", "gemm256_f16_desc_kernel<3"),
                              ("encode", "layernorm", "ln_kernel"), ("encode", "attention", "attention_kernel"),
                              ("search", "ip_topk_fast", "ip_topk_fast_kernel<false, false>"), ("search", "ip_topk_rescore", "rescore_kernel"),
                              ("search", "ip_topk_scan", "ip_topk_scan_kernel")):
