@@ -23,7 +23,7 @@
 //      other, the 16 of an XCD that scan the same corpus split find its tiles in their L2 (hit rate 15 % -> 58 %) and the
 //      256 MB Infinity Cache serves the other XCDs;
 //   5. when the scan is over, rescore_kernel (one wave per list) re-scores the rows within 2 eps of the final k-th best
-//      approximate score with the exact fp32 fmaf chain over k ascending (the contract of oracle/ip_topk_ref.c) -- 64 rows
+//      approximate score (k-th over the list and its neighbour split's list together) with the exact fp32 fmaf chain over k ascending (the contract of oracle/ip_topk_ref.c) -- 64 rows
 //      per round, one per lane, their fp32 data staged through LDS by coalesced 1 KiB LDS-DMAs -- and selects the exact
 //      top-k under (score desc, row asc) from exact keys;
 //   6. topk_finalize merges the splits and, for every duplicate class whose representative survived, adds
@@ -894,8 +894,8 @@ __global__ void __launch_bounds__(F_THREADS, 2) ip_topk_fast_kernel(const FastPa
 
 // ---- exact re-scoring of the lists the filter kernel left: one wave (= one workgroup) per (query, split) ---------------
 // A buffer ends the scan with a few hundred rows (everything above the LAST threshold), but only the rows within 2 eps
-// of the final k-th best approximate score (about k + 66) can be in the exact top-k.  The band is cut first: the k-th
-// approximate key by radix select, the survivors' buffer positions compacted into an LDS list.  Then, 64 rows per
+// of the final k-th best approximate score (about k + 66 per query) can be in the exact top-k.  The band is cut first: the
+// k-th approximate score by radix select over this list and the next split's, the survivors' buffer positions compacted into an LDS list.  Then, 64 rows per
 // round (one per lane), 256 floats of every row at a time: the wave copies the 64 row pieces into LDS with one
 // 1 KiB LDS-DMA each -- every lane reading its own row straight from memory made 64 scattered 16-byte requests per
 // load instruction and ran at 1.3 TB/s -- and each lane runs the canonical fmaf chain (k ascending) over its row's
@@ -917,7 +917,7 @@ constexpr int RS_CHUNK = 256;            // floats of a row staged per step
 constexpr int RS_STRIDE = RS_CHUNK + 4;  // floats between the staged pieces of consecutive rows
 inline size_t rescore_lds_bytes(int d) { return ((size_t)d + F_C / 2 + 64 * RS_STRIDE) * sizeof(float); }
 
-__global__ void __launch_bounds__(64) rescore_kernel(const RescoreParams P) {
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) rescore_kernel(const RescoreParams P) {  // LDS allows 2 waves per CU
     extern __shared__ __attribute__((aligned(16))) float rs_smem[];
     const int l = threadIdx.x;
     const int d = P.d;
@@ -946,16 +946,43 @@ __global__ void __launch_bounds__(64) rescore_kernel(const RescoreParams P) {
     }
     float thr_band = P.thr_g[lid];  // rows buffered before the threshold rose (own prunes, other splits) are out as well
     if (!(thr_band == thr_band)) thr_band = -INFINITY;
-    if (n_c > P.k) {
-        u64 T = 0;  // k-th largest approximate key
-        for (int bit = 63; bit >= 0; --bit) {
-            const u64 t2 = T | (1ull << bit);
+    // The k-th best approximate score is taken over this list AND the list of the next split of the same query (with two
+    // splits: over everything the filter kept for the query): a threshold from any subset of the rows is valid for all of
+    // them, and the union's k-th is what the merged answer is cut at -- each list then keeps its share of the ~k + 66
+    // band rows instead of k + 66 of its own.  Only the score halves of the keys take part (32 radix steps).
+    const int n_own = (n_c + 63) >> 6;  // registers in use (wave-uniform)
+    uint32_t sib[F_NPL];
+    int n_c2 = 0, n_sib = 0;
+    if (P.S > 1) {
+        const size_t lid2 = (ts - split + (size_t)((split + 1) % P.S)) * FQ + ql;
+        n_c2 = min(P.cnt_g[lid2], F_C);
+        n_sib = (n_c2 + 63) >> 6;
+        const u64 *cq2 = P.cand + lid2 * (size_t)F_C;
+#pragma unroll
+        for (int j = 0; j < F_NPL; ++j) {
+            const int idx = j * 64 + l;
+            sib[j] = (idx < n_c2) ? (uint32_t)(cq2[idx] >> 32) : 0u;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < F_NPL; ++j) sib[j] = 0u;
+    }
+    if (n_c + n_c2 >= P.k) {
+        uint32_t T = 0;  // score half of the k-th largest approximate key of the union
+        for (int bit = 31; bit >= 0; --bit) {
+            const uint32_t t2 = T | (1u << bit);
             int ge = 0;
 #pragma unroll
-            for (int j = 0; j < F_NPL; ++j) ge += __popcll(__ballot(keys[j] >= t2));
+            for (int j = 0; j < F_NPL; ++j) {
+                if (j < n_own) ge += __popcll(__ballot((uint32_t)(keys[j] >> 32) >= t2));
+            }
+#pragma unroll
+            for (int j = 0; j < F_NPL; ++j) {
+                if (j < n_sib) ge += __popcll(__ballot(sib[j] >= t2));
+            }
             if (ge >= P.k) T = t2;
         }
-        thr_band = fmaxf(thr_band, key_score(T) - eps2);
+        if (T != 0u) thr_band = fmaxf(thr_band, key_score((u64)T << 32) - eps2);
     }
     int n_band = 0;
 #pragma unroll

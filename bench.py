@@ -480,7 +480,7 @@ def main():
                                           "frac": (ach / PEAK_F16_TF) if ach else None, "traffic": traffic,
                                           "ms_per_launch": scan["ms"] / n_scan,
                                           "rescore_ms_per_launch": resc["ms"] / max(resc["count"], 1),
-                                          "rescore_kernel": "rescore_kernel (exact fp32 fmaf chains of the ~k + 66 band rows per list; "
+                                          "rescore_kernel": "rescore_kernel (exact fp32 fmaf chains of the ~k + 66 band rows per query, shared between its split lists; "
                                                             "HBM-bound gather of 3 KB rows)",
                                           "finalize_ms_per_launch": fin["ms"] / max(fin["count"], 1),
                                           "whole_step_tflops": 2.0 * a.query_block * a.n_passages * 768 * a.steps / dt / 1e12,
