@@ -5,7 +5,7 @@
 namespace ance {
 
 struct AttnArgs {
-    const _Float16 *qk;    // [T, 2 H]: Q (pre-scaled by 1/sqrt(64)) | K, row stride ld_qk
+    const _Float16 *qk;    // [T, 2 H]: Q (pre-scaled by log2(e)/sqrt(64): the softmax runs on exp2) | K, row stride ld_qk
     const _Float16 *vt;    // [H, ld_vt]: V^T, row = head * 64 + dim, column = seq_vtcol[s] + key
     _Float16 *ctx;         // [T, H], row stride ld_ctx
     const int *seq_off;    // [n_seq + 1] first token of each sequence in the packed batch

@@ -17,6 +17,19 @@
 // [CLS] gather, the head) recompute it from the pre-LN row and the two row statistics with the one
 // expression ln_apply4 -- 6 KB per token and layer less HBM traffic (LayerNorm kernel 72 -> ~46 us).
 // Precision: fp16 MFMA operands, fp32 accumulation, fp32 residual stream / LayerNorm / softmax.
+//
+// "LayerNorm without a kernel" (default; ANCE_LN_FOLD=0 selects the form above): the two LayerNorm passes of a layer
+// read 3 KB and write 1.5 KB per token at the HBM roofline for arithmetic every consumer can do on the fly.  Instead
+//   * the RES GEMM epilogue (EPI_RESLN) writes its output row v as an fp16 pair (hi = fp16(v), lo = fp16(v - hi): the same
+//     3 KB the fp32 row took, 22 mantissa bits) and the (mean, M2) of every 64-column slice; ln_finalize_kernel (T rows x
+//     96 bytes) combines the 12 slices of a row into (mean, rstd);
+//   * the consumer GEMMs take hi AS IT IS for their token operand and finish the normalisation algebraically:
+//       LN(v) W^T + b = r (v (gamma (.) W)^T - mu c) + (b + W beta),   c[n] = sum_k fp16(gamma_k W[n][k])
+//     with gamma folded into the fp16 weight when it is loaded, c summed over the ROUNDED weights (so that the identity is
+//     exact for the products the MFMA actually forms) and b' in fp32;
+//   * the consumers of the fp32 value (next RES epilogue, [CLS] gather, head) recompute LN(hi + lo) as before.
+// Rounding points that move: the token operand is fp16(v) instead of fp16(LN(v)) -- the same relative rounding of every
+// element, taken before the mean is removed -- and gamma (.) W is rounded once instead of W.  Measured parity: DESIGN.md 4.
 #include <stdlib.h>
 #include <string.h>
 #include <vector>
@@ -260,7 +273,8 @@ __global__ void __launch_bounds__(256) gather_cls_kernel(const float *pre, const
     }
 }
 
-__global__ void __launch_bounds__(256) head_kernel(const float *pre, const float *stats, const float *lng, const float *lnb,
+__global__ void __launch_bounds__(256) head_kernel(const float *pre, const _Float16 *hi, const _Float16 *lo, const float *stats,
+                                                   const float *lng, const float *lnb,
                                                    const int *seq_off, int compact, const float *W, const float *b,
                                                    const float *gamma, const float *beta, int has_head, float *out) {
     __shared__ float cls[H];
@@ -268,14 +282,14 @@ __global__ void __launch_bounds__(256) head_kernel(const float *pre, const float
     __shared__ float red[8];
     const int s = blockIdx.x, tid = threadIdx.x;
     const size_t row = (size_t)(compact ? s : seq_off[s]);  // compact: row s already is the [CLS] row
-    const float *src = pre + row * H;
     const float mean_h = stats[2 * row], rstd_h = stats[2 * row + 1];  // h = LN(pre), recomputed (file header)
     float *dst = out + (size_t)s * HEAD_OUT;
+    auto src = [&](int j) { return hi ? (float)hi[row * H + j] + (float)lo[row * H + j] : pre[row * H + j]; };
     if (!has_head) {
-        for (int j = tid; j < H; j += 256) dst[j] = (src[j] - mean_h) * rstd_h * lng[j] + lnb[j];
+        for (int j = tid; j < H; j += 256) dst[j] = (src(j) - mean_h) * rstd_h * lng[j] + lnb[j];
         return;
     }
-    for (int j = tid; j < H; j += 256) cls[j] = (src[j] - mean_h) * rstd_h * lng[j] + lnb[j];
+    for (int j = tid; j < H; j += 256) cls[j] = (src(j) - mean_h) * rstd_h * lng[j] + lnb[j];
     __syncthreads();
     // each wave computes output features n = w, w+4, ...: lanes split k, reduce by shuffle
     const int w = tid >> 6, l = tid & 63;
@@ -309,11 +323,237 @@ __global__ void __launch_bounds__(256) head_kernel(const float *pre, const float
     for (int j = tid; j < HEAD_OUT; j += 256) dst[j] = (z[j] - mean) * rstd * gamma[j] + beta[j];
 }
 
+
+// ---- folded-LayerNorm path ---------------------------------------------------------------------
+__device__ __forceinline__ void split_store(const f32x4 v, _Float16 *hi, _Float16 *lo, int c4) {
+    const f16x4 h = f16x4{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+    const f16x4 r = f16x4{(_Float16)(v[0] - (float)h[0]), (_Float16)(v[1] - (float)h[1]), (_Float16)(v[2] - (float)h[2]),
+                          (_Float16)(v[3] - (float)h[3])};
+    reinterpret_cast<f16x4 *>(hi)[c4] = h;
+    reinterpret_cast<f16x4 *>(lo)[c4] = r;
+}
+__device__ __forceinline__ f32x4 pair_load(const _Float16 *hi, const _Float16 *lo, int c4) {
+    const f16x4 h = reinterpret_cast<const f16x4 *>(hi)[c4], r = reinterpret_cast<const f16x4 *>(lo)[c4];
+    return f32x4{(float)h[0] + (float)r[0], (float)h[1] + (float)r[1], (float)h[2] + (float)r[2], (float)h[3] + (float)r[3]};
+}
+
+// embeddings -> (hi, lo) pair of the pre-LayerNorm row + its (mean, rstd); one wave per token
+__global__ void __launch_bounds__(256) embed_fold_kernel(const int *tok_id, const int *tok_pos, int Tpad, const float *word,
+                                                         const float *pos, const float *type0, int vocab, int max_pos, float eps,
+                                                         _Float16 *hi, _Float16 *lo, float *stats) {
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int l = threadIdx.x & 63;
+    if (t >= Tpad) return;
+    int id = tok_id[t], p = tok_pos[t];
+    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+    p = p < 0 ? 0 : (p >= max_pos ? max_pos - 1 : p);
+    const f32x4 *w4 = reinterpret_cast<const f32x4 *>(word + (size_t)id * H);
+    const f32x4 *p4 = reinterpret_cast<const f32x4 *>(pos + (size_t)p * H);
+    const f32x4 *t4 = reinterpret_cast<const f32x4 *>(type0);
+    f32x4 v[3];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int c4 = k * 64 + l;
+        v[k] = (w4[c4] + t4[c4]) + p4[c4];  // same association as the reference: (word + type) + pos
+        split_store(v[k], hi + (size_t)t * H, lo + (size_t)t * H, c4);
+        s += (v[k][0] + v[k][1]) + (v[k][2] + v[k][3]);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    const float mean = s * (1.0f / H);
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float a = v[k][j] - mean;
+            q += a * a;
+        }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) q += __shfl_xor(q, off);
+    if (l == 0) {
+        stats[2 * (size_t)t] = mean;
+        stats[2 * (size_t)t + 1] = rsqrtf(q * (1.0f / H) + eps);
+    }
+}
+
+// (mean, M2) of the n_parts 64-column slices of a row (EPI_RESLN) -> (mean, rstd) of the row.  Chan's combination
+// with equal counts: mean = avg(mean_i), M2 = sum M2_i + 64 sum (mean_i - mean)^2.  One thread per row.
+__global__ void __launch_bounds__(256) ln_finalize_kernel(const float *part, int n_parts, int rows, float eps, float *stats) {
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= rows) return;
+    const float2 *pp = reinterpret_cast<const float2 *>(part) + (size_t)r * n_parts;
+    float m = 0.f, q = 0.f;
+    for (int j = 0; j < n_parts; ++j) m += pp[j].x;
+    m *= 1.0f / (float)n_parts;
+    for (int j = 0; j < n_parts; ++j) {
+        const float d = pp[j].x - m;
+        q += pp[j].y + 64.0f * d * d;
+    }
+    reinterpret_cast<float2 *>(stats)[r] = make_float2(m, rsqrtf(q / (64.0f * (float)n_parts) + eps));
+}
+
+// last layer, CLS-only tail: compact (hi, lo, stats) rows of the [CLS] tokens; rows S..S_pad zeroed
+__global__ void __launch_bounds__(256) gather_cls_fold_kernel(const _Float16 *hi, const _Float16 *lo, const float *stats,
+                                                              const int *seq_off, int S, int S_pad, _Float16 *chi, _Float16 *clo,
+                                                              float *cstats) {
+    const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int l = threadIdx.x & 63;
+    if (s >= S_pad) return;
+    f16x4 *dh = reinterpret_cast<f16x4 *>(chi + (size_t)s * H), *dl = reinterpret_cast<f16x4 *>(clo + (size_t)s * H);
+    if (s < S) {
+        const size_t row = (size_t)seq_off[s];
+        const f16x4 *sh = reinterpret_cast<const f16x4 *>(hi + row * H), *sl = reinterpret_cast<const f16x4 *>(lo + row * H);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            dh[k * 64 + l] = sh[k * 64 + l];
+            dl[k * 64 + l] = sl[k * 64 + l];
+        }
+        if (l == 0) {
+            cstats[2 * s] = stats[2 * row];
+            cstats[2 * s + 1] = stats[2 * row + 1];
+        }
+    } else {
+        const f16x4 z = {0, 0, 0, 0};
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            dh[k * 64 + l] = z;
+            dl[k * 64 + l] = z;
+        }
+        if (l == 0) {
+            cstats[2 * s] = 0.f;
+            cstats[2 * s + 1] = 0.f;
+        }
+    }
+}
+
+// weight load with the LayerNorm folded in (K = 768 columns): W16[n][k] = fp16(gamma[k] W[n][k]),
+// csum[n] = sum_k W16[n][k] (over the ROUNDED values), bout[n] = b[n] + sum_k beta[k] W[n][k].  One wave per row.
+__global__ void __launch_bounds__(256) fold_weight_kernel(const float *W, const float *b, const float *gamma, const float *beta,
+                                                          int N, _Float16 *W16, float *csum, float *bout) {
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int l = threadIdx.x & 63;
+    if (n >= N) return;
+    const f32x4 *w4 = reinterpret_cast<const f32x4 *>(W + (size_t)n * H);
+    float cs = 0.f, bs = 0.f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int c4 = k * 64 + l;
+        const f32x4 w = w4[c4], g = reinterpret_cast<const f32x4 *>(gamma)[c4], be = reinterpret_cast<const f32x4 *>(beta)[c4];
+        const f16x4 h = f16x4{(_Float16)(g[0] * w[0]), (_Float16)(g[1] * w[1]), (_Float16)(g[2] * w[2]), (_Float16)(g[3] * w[3])};
+        reinterpret_cast<f16x4 *>(W16 + (size_t)n * H)[c4] = h;
+        cs += ((float)h[0] + (float)h[1]) + ((float)h[2] + (float)h[3]);
+        bs += (be[0] * w[0] + be[1] * w[1]) + (be[2] * w[2] + be[3] * w[3]);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        cs += __shfl_xor(cs, off);
+        bs += __shfl_xor(bs, off);
+    }
+    if (l == 0) {
+        csum[n] = cs;
+        bout[n] = b[n] + bs;
+    }
+}
+
+// ---- embeddingHead as one fp32 MFMA GEMM over the [CLS] rows (model/models.py:145-152) ----------
+// z[s][n] = sum_k LN(cls_s)[k] W[n][k] + b[n]; 32 sequences x 128 features per workgroup, one 32 x 32 tile per wave
+// (v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulation in k order).  The 32 normalised [CLS] rows are staged
+// once in LDS (96.5 KiB); W rows stream from L2 as 16-byte pieces per lane.  A block per sequence re-read the whole
+// 2.36 MB W (2 GB of L2 reads per 883 rows, 166 us); this reads it 28 times.
+constexpr int HEAD_LDA = H + 4;  // floats; 16 lanes x stride 4 banks: conflict-free ds_read_b128
+constexpr size_t HEAD_LDS_BYTES = (size_t)32 * HEAD_LDA * sizeof(float);
+
+__global__ void __launch_bounds__(256) head_gemm_kernel(const float *pre32, const _Float16 *hi, const _Float16 *lo,
+                                                        const float *stats, const float *lng, const float *lnb, const int *seq_off,
+                                                        int compact, int S, const float *W, const float *b, float *out) {
+    extern __shared__ __attribute__((aligned(16))) float cls[];
+    const int s0 = blockIdx.x * 32, n0 = blockIdx.y * 128;
+    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, g = l >> 5, i = l & 31;
+    // stage LN(pre)[cls] of 32 sequences: wave w takes rows w, w + 4, ...
+    for (int r = w; r < 32; r += 4) {
+        const int s = s0 + r;
+        f32x4 *dst = reinterpret_cast<f32x4 *>(cls + r * HEAD_LDA);
+        if (s < S) {
+            const size_t row = (size_t)(compact ? s : seq_off[s]);
+            const float mean = stats[2 * row], rstd = stats[2 * row + 1];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const int c4 = k * 64 + l;
+                const f32x4 x = hi ? pair_load(hi + row * H, lo + row * H, c4)
+                                   : reinterpret_cast<const f32x4 *>(pre32 + row * H)[c4];
+                dst[c4] = ln_apply4(x, mean, rstd, reinterpret_cast<const f32x4 *>(lng)[c4],
+                                    reinterpret_cast<const f32x4 *>(lnb)[c4]);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) dst[k * 64 + l] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    __syncthreads();
+    // MFMA rows (A operand) = sequences, columns (B operand) = features n0 + 32 w + i; k-step j of a 16-byte piece uses
+    // k = 8 s' + 4 g + j on both sides
+    const float *ap = cls + i * HEAD_LDA + 4 * g;
+    const float *wp = W + (size_t)(n0 + 32 * w + i) * H + 4 * g;
+    f32x16 acc = {0};
+#pragma unroll 4
+    for (int kk = 0; kk < H / 8; ++kk) {
+        const f32x4 a = *reinterpret_cast<const f32x4 *>(ap + kk * 8);
+        const f32x4 bb = *reinterpret_cast<const f32x4 *>(wp + kk * 8);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], bb[j], acc, 0, 0, 0);
+    }
+    // acc[r]: sequence s0 + (r & 3) + 8 (r >> 2) + 4 g, feature n0 + 32 w + i
+    const int n = n0 + 32 * w + i;
+    const float bias = b[n];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int s = s0 + (r & 3) + 8 * (r >> 2) + 4 * g;
+        if (s < S) out[(size_t)s * HEAD_OUT + n] = acc[r] + bias;
+    }
+}
+
+// final LayerNorm (model/models.py:146,152 "norm") of the head output, in place; one wave per sequence
+__global__ void __launch_bounds__(256) head_ln_kernel(float *out, int S, const float *gamma, const float *beta) {
+    const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int l = threadIdx.x & 63;
+    if (s >= S) return;
+    f32x4 *z4 = reinterpret_cast<f32x4 *>(out + (size_t)s * HEAD_OUT);
+    f32x4 v[3];
+    float sm = 0.f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        v[k] = z4[k * 64 + l];
+        sm += (v[k][0] + v[k][1]) + (v[k][2] + v[k][3]);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sm += __shfl_xor(sm, off);
+    const float mean = sm * (1.0f / HEAD_OUT);
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float a = v[k][j] - mean;
+            q += a * a;
+        }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) q += __shfl_xor(q, off);
+    const float rstd = rsqrtf(q * (1.0f / HEAD_OUT) + 1e-5f);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int c4 = k * 64 + l;
+        z4[c4] = ln_apply4(v[k], mean, rstd, reinterpret_cast<const f32x4 *>(gamma)[c4], reinterpret_cast<const f32x4 *>(beta)[c4]);
+    }
+}
+
 // ------------------------------------------------------------------------------- host layout --
 
 struct LayerW {
     _Float16 *wqk, *wv, *wo, *w1, *w2;
     float *bqk, *bv, *bo, *b1, *b2, *ln1w, *ln1b, *ln2w, *ln2b;
+    float *cqk, *cv, *c1;  // folded LayerNorm: per-feature sums of the folded fp16 weight rows
 };
 
 struct Arena {
@@ -348,12 +588,18 @@ struct AnceEncoder {
         float *preA, *preB;      // pre-LayerNorm rows: attention block output / FFN block output (or embeddings)
         float *statsA, *statsB;  // (mean, rstd) per row of preA / preB
         _Float16 *h16, *qk16, *vt16, *ctx16, *ffn16;
+        float *part;             // folded LayerNorm: (mean, M2) of the 64-column slices of the last RES output
+        // folded LayerNorm: preA / preB hold the (hi, lo) fp16 pairs of the stream instead of fp32 rows
+        _Float16 *xa_hi() const { return reinterpret_cast<_Float16 *>(preA); }
+        _Float16 *xb_hi() const { return reinterpret_cast<_Float16 *>(preB); }
     } lane[MAX_LANES];
     int n_lanes;
     hipStream_t side[MAX_LANES];
     hipEvent_t ev_fork, ev_join[MAX_LANES];
     std::vector<int32_t> host_lens;
     bool cls_tail;  // run the last layer's post-attention part on the [CLS] rows only (ANCE_CLS_TAIL=0 disables)
+    bool ln_fold;   // LayerNorm folded into the GEMMs (file header; ANCE_LN_FOLD=0 disables)
+    bool head_mfma; // embeddingHead as one fp32 MFMA GEMM (ANCE_HEAD_MFMA=0: one block per sequence)
 };
 
 namespace {
@@ -388,6 +634,9 @@ void layout_weights(const AnceEncoderDesc *d, Arena &a, AnceEncoder *e) {
         w.b2 = a.take<float>(H);
         w.ln2w = a.take<float>(H);
         w.ln2b = a.take<float>(H);
+        w.cqk = a.take<float>(2 * H);
+        w.cv = a.take<float>(H);
+        w.c1 = a.take<float>(I);
         if (e) e->layers[i] = w;
     }
     float *hw = nullptr, *hb = nullptr, *nw = nullptr, *nb = nullptr;
@@ -419,6 +668,7 @@ void layout_workspace(const AnceEncoderDesc *d, Arena &a, AnceEncoder *e) {
         L.vt16 = a.take<_Float16>((size_t)H * vcap);
         L.ctx16 = a.take<_Float16>((size_t)tcap * H);
         L.ffn16 = a.take<_Float16>((size_t)tcap * d->intermediate);
+        L.part = a.take<float>((size_t)tcap * (H / 64) * 2);
         if (e) e->lane[ln] = L;
     }
 }
@@ -510,10 +760,18 @@ int encode_impl(AnceEncoder *e, const int32_t *base, int64_t ld, const int32_t *
                 const int nb_seq = (S + 3) / 4, nb_pad = (Tpad - T + 255) / 256;
                 hipLaunchKernelGGL(pack_kernel, dim3(nb_seq > nb_pad ? nb_seq : nb_pad), dim3(256), 0, st, P);
             }
+            const bool fold = e->ln_fold;
+            // folded LayerNorm: the two halves of the fp16 pair of a stream share the fp32 row's 3 KB
+            _Float16 *const xa_hi = LN.xa_hi(), *const xa_lo = xa_hi + (size_t)e->tcap * H;
+            _Float16 *const xb_hi = LN.xb_hi(), *const xb_lo = xb_hi + (size_t)e->tcap * H;
             {
             ProfScope pe(PC_EMBED, st);
-            hipLaunchKernelGGL(embed_ln_kernel, dim3(Tpad / 4), dim3(256), 0, st, LN.tok_id, LN.tok_pos, Tpad, e->word, e->pos,
-                               e->type0, D.vocab_size, D.max_position, e->eln_w, e->eln_b, D.ln_eps, LN.preB, LN.h16, LN.statsB);
+            if (fold)
+                hipLaunchKernelGGL(embed_fold_kernel, dim3(Tpad / 4), dim3(256), 0, st, LN.tok_id, LN.tok_pos, Tpad, e->word, e->pos,
+                                   e->type0, D.vocab_size, D.max_position, D.ln_eps, xb_hi, xb_lo, LN.statsB);
+            else
+                hipLaunchKernelGGL(embed_ln_kernel, dim3(Tpad / 4), dim3(256), 0, st, LN.tok_id, LN.tok_pos, Tpad, e->word, e->pos,
+                                   e->type0, D.vocab_size, D.max_position, e->eln_w, e->eln_b, D.ln_eps, LN.preB, LN.h16, LN.statsB);
             }
             // Only the [CLS] row of the last layer reaches the head (model/models.py:49,152): after the
             // last layer's K / V projections everything runs on the S compact [CLS] rows.
@@ -527,21 +785,24 @@ int encode_impl(AnceEncoder *e, const int32_t *base, int64_t ld, const int32_t *
                 GemmArgs G;
                 memset(&G, 0, sizeof(G));
                 // Q | K projection
-                G.A = LN.h16; G.lda = H; G.B = W.wqk; G.ldb = H; G.M = Tpad; G.N = 2 * H; G.K = H;
-                G.bias = W.bqk; G.out16 = LN.qk16; G.ldc = 2 * H; G.scale = 0.125f; G.scale_cols = H;
+                G.A = fold ? xb_hi : LN.h16; G.lda = H; G.B = W.wqk; G.ldb = H; G.M = Tpad; G.N = 2 * H; G.K = H;
+                G.bias = W.bqk; G.out16 = LN.qk16; G.ldc = 2 * H; G.scale_cols = H;
+                G.scale = 0.125f * 1.44269504088896340736f;  // 1/sqrt(64) and log2(e): the softmax runs on exp2
+                G.row_stats = LN.statsB; G.csum = W.cqk;
                 int rc;
                 {
                     ProfScope ps(PC_GEMM_QK, st, 2.0 * T * (2.0 * H) * H);
-                    rc = launch_gemm_f16(EPI_QK, G, st);
+                    rc = launch_gemm_f16(fold ? EPI_QK_F : EPI_QK, G, st);
                 }
                 if (rc) return rc;
                 // V^T = Wv h^T
                 memset(&G, 0, sizeof(G));
-                G.A = W.wv; G.lda = H; G.B = LN.h16; G.ldb = H; G.M = H; G.N = Tpad; G.K = H;
+                G.A = W.wv; G.lda = H; G.B = fold ? xb_hi : LN.h16; G.ldb = H; G.M = H; G.N = Tpad; G.K = H;
                 G.bias = W.bv; G.out16 = LN.vt16; G.ldc = ldvt; G.col_map = LN.tok_vtcol; G.n_valid = T;
+                G.row_stats = LN.statsB; G.csum = W.cv;
                 {
                     ProfScope ps(PC_GEMM_VT, st, 2.0 * T * (double)H * H);
-                    rc = launch_gemm_f16(EPI_VT, G, st);
+                    rc = launch_gemm_f16(fold ? EPI_VT_F : EPI_VT, G, st);
                 }
                 if (rc) return rc;
                 AttnArgs A;
@@ -557,57 +818,93 @@ int encode_impl(AnceEncoder *e, const int32_t *base, int64_t ld, const int32_t *
                 const float *rg = li == 0 ? e->eln_w : e->layers[li - 1].ln2w;
                 const float *rb = li == 0 ? e->eln_b : e->layers[li - 1].ln2b;
                 memset(&G, 0, sizeof(G));
-                G.res32 = LN.preB; G.res_stats = LN.statsB; G.res_gamma = rg; G.res_beta = rb;
-                if (tail) {  // compact residual rows (already normalised), parked in the (currently dead) FFN buffer
-                    float *rc = reinterpret_cast<float *>(LN.ffn16);
-                    ProfScope ps(PC_LN, st);
-                    hipLaunchKernelGGL(gather_cls_kernel, dim3(S_pad / 4), dim3(256), 0, st, LN.preB, LN.statsB, rg, rb, LN.seq_off,
-                                       S, S_pad, rc);
-                    G.res32 = rc; G.res_stats = nullptr;
+                G.res_stats = LN.statsB; G.res_gamma = rg; G.res_beta = rb;
+                if (fold) {
+                    G.res_hi = xb_hi; G.res_lo = xb_lo;
+                    if (tail) {  // compact (hi, lo, stats) rows of the [CLS] tokens, parked in the (currently dead) FFN buffer
+                        _Float16 *chi = LN.ffn16, *clo = chi + (size_t)S_pad * H;
+                        float *cst = reinterpret_cast<float *>(clo + (size_t)S_pad * H);
+                        ProfScope ps(PC_LN, st);
+                        hipLaunchKernelGGL(gather_cls_fold_kernel, dim3(S_pad / 4), dim3(256), 0, st, xb_hi, xb_lo, LN.statsB, LN.seq_off,
+                                           S, S_pad, chi, clo, cst);
+                        G.res_hi = chi; G.res_lo = clo; G.res_stats = cst;
+                    }
+                    G.out16 = xa_hi; G.out_lo = xa_lo; G.part = LN.part;
+                } else {
+                    G.res32 = LN.preB;
+                    if (tail) {  // compact residual rows (already normalised), parked in the (currently dead) FFN buffer
+                        float *rc = reinterpret_cast<float *>(LN.ffn16);
+                        ProfScope ps(PC_LN, st);
+                        hipLaunchKernelGGL(gather_cls_kernel, dim3(S_pad / 4), dim3(256), 0, st, LN.preB, LN.statsB, rg, rb, LN.seq_off,
+                                           S, S_pad, rc);
+                        G.res32 = rc; G.res_stats = nullptr;
+                    }
+                    G.out32 = LN.preA;
                 }
                 G.A = LN.ctx16; G.lda = H; G.B = W.wo; G.ldb = H; G.M = Mrows; G.N = H; G.K = H;
-                G.bias = W.bo; G.out32 = LN.preA; G.ldc = H;
+                G.bias = W.bo; G.ldc = H;
                 {
                     ProfScope ps(PC_GEMM_OUT, st, 2.0 * Mwork * (double)H * H);
-                    rc = launch_gemm_f16(EPI_RES32, G, st);
+                    rc = launch_gemm_f16(fold ? EPI_RESLN : EPI_RES32, G, st);
                 }
                 if (rc) return rc;
                 {
                     ProfScope ps(PC_LN, st);
-                    hipLaunchKernelGGL(ln_kernel, dim3(Mrows / 4), dim3(256), 0, st, LN.preA, Mrows, W.ln1w, W.ln1b, D.ln_eps,
-                                       LN.h16, LN.statsA);
+                    if (fold)
+                        hipLaunchKernelGGL(ln_finalize_kernel, dim3(Mrows / 256), dim3(256), 0, st, LN.part, H / 64, Mrows, D.ln_eps,
+                                           LN.statsA);
+                    else
+                        hipLaunchKernelGGL(ln_kernel, dim3(Mrows / 4), dim3(256), 0, st, LN.preA, Mrows, W.ln1w, W.ln1b, D.ln_eps,
+                                           LN.h16, LN.statsA);
                 }
                 // intermediate.dense + GELU
                 memset(&G, 0, sizeof(G));
-                G.A = LN.h16; G.lda = H; G.B = W.w1; G.ldb = H; G.M = Mrows; G.N = I; G.K = H;
+                G.A = fold ? xa_hi : LN.h16; G.lda = H; G.B = W.w1; G.ldb = H; G.M = Mrows; G.N = I; G.K = H;
                 G.bias = W.b1; G.out16 = LN.ffn16; G.ldc = I;
+                G.row_stats = LN.statsA; G.csum = W.c1;
                 {
                     ProfScope ps(PC_GEMM_FFN1, st, 2.0 * Mwork * (double)I * H);
-                    rc = launch_gemm_f16(EPI_GELU, G, st);
+                    rc = launch_gemm_f16(fold ? EPI_GELU_F : EPI_GELU, G, st);
                 }
                 if (rc) return rc;
                 // output.dense + residual
                 memset(&G, 0, sizeof(G));
                 G.A = LN.ffn16; G.lda = I; G.B = W.w2; G.ldb = I; G.M = Mrows; G.N = H; G.K = I;
-                G.bias = W.b2; G.out32 = LN.preB; G.ldc = H;
-                G.res32 = LN.preA; G.res_stats = LN.statsA; G.res_gamma = W.ln1w; G.res_beta = W.ln1b;
+                G.bias = W.b2; G.ldc = H;
+                G.res_stats = LN.statsA; G.res_gamma = W.ln1w; G.res_beta = W.ln1b;
+                if (fold) {
+                    G.res_hi = xa_hi; G.res_lo = xa_lo; G.out16 = xb_hi; G.out_lo = xb_lo; G.part = LN.part;
+                } else {
+                    G.res32 = LN.preA; G.out32 = LN.preB;
+                }
                 {
                     ProfScope ps(PC_GEMM_FFN2, st, 2.0 * Mwork * (double)I * H);
-                    rc = launch_gemm_f16(EPI_RES32, G, st);
+                    rc = launch_gemm_f16(fold ? EPI_RESLN : EPI_RES32, G, st);
                 }
                 if (rc) return rc;
                 {
                     ProfScope ps(PC_LN, st);
-                    hipLaunchKernelGGL(ln_kernel, dim3(Mrows / 4), dim3(256), 0, st, LN.preB, Mrows, W.ln2w, W.ln2b, D.ln_eps,
-                                       LN.h16, LN.statsB);
+                    if (fold)
+                        hipLaunchKernelGGL(ln_finalize_kernel, dim3(Mrows / 256), dim3(256), 0, st, LN.part, H / 64, Mrows, D.ln_eps,
+                                           LN.statsB);
+                    else
+                        hipLaunchKernelGGL(ln_kernel, dim3(Mrows / 4), dim3(256), 0, st, LN.preB, Mrows, W.ln2w, W.ln2b, D.ln_eps,
+                                           LN.h16, LN.statsB);
                 }
             }
             {
                 ProfScope ps(PC_HEAD, st);
                 const LayerW &WL = e->layers[D.n_layers - 1];
-                hipLaunchKernelGGL(head_kernel, dim3(S), dim3(256), 0, st, LN.preB, LN.statsB, WL.ln2w, WL.ln2b, LN.seq_off,
-                                   cls_tail ? 1 : 0, e->head_w, e->head_b,
-                                   e->norm_w, e->norm_b, D.has_head, d_out + (size_t)(r0 * n_chunks + gs) * HEAD_OUT);
+                float *dst = d_out + (size_t)(r0 * n_chunks + gs) * HEAD_OUT;
+                const _Float16 *hh = fold ? xb_hi : nullptr, *hl = fold ? xb_lo : nullptr;
+                if (D.has_head && e->head_mfma) {
+                    hipLaunchKernelGGL(head_gemm_kernel, dim3((S + 31) / 32, HEAD_OUT / 128), dim3(256), HEAD_LDS_BYTES, st, LN.preB, hh,
+                                       hl, LN.statsB, WL.ln2w, WL.ln2b, LN.seq_off, cls_tail ? 1 : 0, S, e->head_w, e->head_b, dst);
+                    hipLaunchKernelGGL(head_ln_kernel, dim3((S + 3) / 4), dim3(256), 0, st, dst, S, e->norm_w, e->norm_b);
+                } else {
+                    hipLaunchKernelGGL(head_kernel, dim3(S), dim3(256), 0, st, LN.preB, hh, hl, LN.statsB, WL.ln2w, WL.ln2b, LN.seq_off,
+                                       cls_tail ? 1 : 0, e->head_w, e->head_b, e->norm_w, e->norm_b, D.has_head, dst);
+                }
             }
             gs = g;
         }
@@ -668,6 +965,10 @@ extern "C" int ance_encoder_create(const AnceEncoderDesc *desc, const void *cons
     {
         const char *ct = getenv("ANCE_CLS_TAIL");
         e->cls_tail = !(ct && ct[0] == '0');
+        const char *lf = getenv("ANCE_LN_FOLD");
+        e->ln_fold = !(lf && lf[0] == '0');
+        const char *hm = getenv("ANCE_HEAD_MFMA");
+        e->head_mfma = !(hm && hm[0] == '0');
         const char *ns = getenv("ANCE_ENCODER_STREAMS");
         e->n_lanes = (ns && ns[0] >= '1' && ns[0] <= '0' + MAX_LANES) ? ns[0] - '0' : 2;
     }
@@ -686,6 +987,11 @@ extern "C" int ance_encoder_create(const AnceEncoderDesc *desc, const void *cons
             return check_launch("ance_encoder_create: streams");
         }
     }
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(head_gemm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)HEAD_LDS_BYTES) != hipSuccess) {  // per device: set for the device this handle lives on
+        delete e;
+        return check_launch("ance_encoder_create: head attr");
+    }
     Arena wa, xa;
     wa.base = reinterpret_cast<char *>(align_up((uintptr_t)d_weight_arena, 256));
     xa.base = reinterpret_cast<char *>(align_up((uintptr_t)d_workspace, 256));
@@ -703,18 +1009,33 @@ extern "C" int ance_encoder_create(const AnceEncoderDesc *desc, const void *cons
     for (int i = 0; i < desc->n_layers; ++i) {
         const void *const *p = w + 5 + 16 * i;
         LayerW &L = e->layers[i];
-        cvt16(p[0], L.wqk, (size_t)H * H, st);                 // query
-        cvt16(p[2], L.wqk + (size_t)H * H, (size_t)H * H, st);  // key
-        cpy32(p[1], L.bqk, H, st);
-        cpy32(p[3], L.bqk + H, H, st);
-        cvt16(p[4], L.wv, (size_t)H * H, st);
-        cpy32(p[5], L.bv, H, st);
+        if (e->ln_fold) {
+            // the LayerNorm that produces this layer's input: embeddings.LayerNorm or the previous output.LayerNorm
+            const float *gin = (const float *)(i == 0 ? w[3] : w[5 + 16 * (i - 1) + 14]);
+            const float *bin = (const float *)(i == 0 ? w[4] : w[5 + 16 * (i - 1) + 15]);
+            auto foldw = [&](const void *W, const void *b, const float *g, const float *be, int N, _Float16 *W16, float *cs,
+                             float *bo) {
+                hipLaunchKernelGGL(fold_weight_kernel, dim3((N + 3) / 4), dim3(256), 0, st, (const float *)W, (const float *)b, g,
+                                   be, N, W16, cs, bo);
+            };
+            foldw(p[0], p[1], gin, bin, H, L.wqk, L.cqk, L.bqk);                                     // query
+            foldw(p[2], p[3], gin, bin, H, L.wqk + (size_t)H * H, L.cqk + H, L.bqk + H);            // key
+            foldw(p[4], p[5], gin, bin, H, L.wv, L.cv, L.bv);                                        // value
+            foldw(p[10], p[11], (const float *)p[8], (const float *)p[9], (int)I, L.w1, L.c1, L.b1);  // intermediate.dense
+        } else {
+            cvt16(p[0], L.wqk, (size_t)H * H, st);                 // query
+            cvt16(p[2], L.wqk + (size_t)H * H, (size_t)H * H, st);  // key
+            cpy32(p[1], L.bqk, H, st);
+            cpy32(p[3], L.bqk + H, H, st);
+            cvt16(p[4], L.wv, (size_t)H * H, st);
+            cpy32(p[5], L.bv, H, st);
+            cvt16(p[10], L.w1, I * H, st);
+            cpy32(p[11], L.b1, I, st);
+        }
         cvt16(p[6], L.wo, (size_t)H * H, st);
         cpy32(p[7], L.bo, H, st);
         cpy32(p[8], L.ln1w, H, st);
         cpy32(p[9], L.ln1b, H, st);
-        cvt16(p[10], L.w1, I * H, st);
-        cpy32(p[11], L.b1, I, st);
         cvt16(p[12], L.w2, (size_t)H * I, st);
         cpy32(p[13], L.b2, H, st);
         cpy32(p[14], L.ln2w, H, st);

@@ -59,7 +59,16 @@ __device__ __forceinline__ void epi_sync() {
     }
 }
 
-template <int EPI, bool WAVE_SYNC = false>
+// sum over the 16 lanes of a DPP row (the 16 lanes that cover one 64-float row segment in the read-back passes)
+__device__ __forceinline__ float row16_sum(float x) {
+    x += __builtin_amdgcn_update_dpp(0.f, x, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
+    x += __builtin_amdgcn_update_dpp(0.f, x, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
+    x += __builtin_amdgcn_update_dpp(0.f, x, 0x124, 0xF, 0xF, true);  // row_ror:4
+    x += __builtin_amdgcn_update_dpp(0.f, x, 0x128, 0xF, 0xF, true);  // row_ror:8
+    return x;
+}
+
+template <int EPI_, bool WAVE_SYNC = false>
 __device__ __forceinline__ void gemm256_epilogue(const GemmArgs &G, f32x16 (&acc)[2][4], float *smem_f, int m0, int n0,
                                                  int w, int l) {
     _Float16 *smem = reinterpret_cast<_Float16 *>(smem_f);
@@ -67,6 +76,8 @@ __device__ __forceinline__ void gemm256_epilogue(const GemmArgs &G, f32x16 (&acc
     const int wm = w >> 2, wn = w & 3;
     // acc[x][y][r]: n = n0 + wn*64 + x*32 + (r&3) + 8*(r>>2) + 4*g ;  m = m0 + wm*128 + y*32 + i
     const int mw0 = m0 + wm * 128, nw0 = n0 + wn * 64;
+    constexpr bool FOLD = EPI_ == EPI_QK_F || EPI_ == EPI_GELU_F || EPI_ == EPI_VT_F;
+    constexpr int EPI = EPI_ == EPI_QK_F ? EPI_QK : EPI_ == EPI_GELU_F ? EPI_GELU : EPI_ == EPI_VT_F ? EPI_VT : EPI_;
     if constexpr (EPI == EPI_VT) {
         // Output rows are A-matrix rows m (features, bias per row); columns are tokens n scattered
         // through col_map (per-sequence 8-aligned key columns, so 16-byte stores are impossible in
@@ -84,14 +95,26 @@ __device__ __forceinline__ void gemm256_epilogue(const GemmArgs &G, f32x16 (&acc
 #pragma unroll
             for (int yy = 0; yy < 2; ++yy) {
                 const float bias = G.bias[mw0 + (2 * p + yy) * 32 + i];
+                float cs = 0.f;
+                if constexpr (FOLD) cs = G.csum[mw0 + (2 * p + yy) * 32 + i];
 #pragma unroll
                 for (int x = 0; x < 2; ++x)
 #pragma unroll
                     for (int rq = 0; rq < 4; ++rq) {
                         const f32x16 &a = acc[x][2 * p + yy];
+                        f32x4 t = f32x4{a[4 * rq], a[4 * rq + 1], a[4 * rq + 2], a[4 * rq + 3]};
+                        if constexpr (FOLD) {  // tokens are the columns: (mean, rstd) of 4 consecutive tokens = 32 bytes
+                            const float *sp = G.row_stats + 2 * (size_t)(nw0 + x * 32 + 8 * rq + 4 * g);
+                            const f32x4 s01 = *reinterpret_cast<const f32x4 *>(sp);
+                            const f32x4 s23 = *reinterpret_cast<const f32x4 *>(sp + 4);
+                            t[0] = (t[0] - s01[0] * cs) * s01[1];
+                            t[1] = (t[1] - s01[2] * cs) * s01[3];
+                            t[2] = (t[2] - s23[0] * cs) * s23[1];
+                            t[3] = (t[3] - s23[2] * cs) * s23[3];
+                        }
                         *reinterpret_cast<f16x4 *>(slab + (yy * 32 + i) * LS + x * 32 + 8 * rq + 4 * g) =
-                            f16x4{(_Float16)(a[4 * rq] + bias), (_Float16)(a[4 * rq + 1] + bias),
-                                  (_Float16)(a[4 * rq + 2] + bias), (_Float16)(a[4 * rq + 3] + bias)};
+                            f16x4{(_Float16)(t[0] + bias), (_Float16)(t[1] + bias), (_Float16)(t[2] + bias),
+                                  (_Float16)(t[3] + bias)};
                     }
             }
             epi_sync<WAVE_SYNC>();
@@ -150,6 +173,65 @@ __device__ __forceinline__ void gemm256_epilogue(const GemmArgs &G, f32x16 (&acc
                 *reinterpret_cast<f32x4 *>(G.out32 + (size_t)(mw0 + y * 32 + rr) * G.ldc + nw0 + c4 * 4) = v + bias + res[it];
             }
         }
+    } else if constexpr (EPI == EPI_RESLN) {
+        // as EPI_RES32, with the residual stream as an fp16 pair: v = acc + bias + LayerNorm(res_hi + res_lo);
+        // out16 = fp16(v) (the next GEMM's token operand AND the high half of the stream), out_lo = fp16(v - out16)
+        // (v - fp16(v) is exact in fp32; the pair carries 22 bits).  Per row and 64-column slice the (mean, M2) of v go
+        // to part[] -- ln_finalize_kernel combines the N / 64 slices of a row (Chan) into (mean, rstd).
+        float *slab = smem_f + w * 4096;
+        constexpr int LS = 68;
+        const int c4 = l & 15;
+        const f32x4 bias = *reinterpret_cast<const f32x4 *>(G.bias + nw0 + c4 * 4);
+        const f32x4 lng = *reinterpret_cast<const f32x4 *>(G.res_gamma + nw0 + c4 * 4);
+        const f32x4 lnb = *reinterpret_cast<const f32x4 *>(G.res_beta + nw0 + c4 * 4);
+        const int n_parts = G.N >> 6, slice = nw0 >> 6;
+#pragma unroll
+        for (int y = 0; y < 4; ++y) {
+            f16x4 rh[8], rl[8];
+            float mean[8], rstd[8];
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int rr = it * 4 + (l >> 4);
+                const size_t row = (size_t)(mw0 + y * 32 + rr);
+                rh[it] = *reinterpret_cast<const f16x4 *>(G.res_hi + row * G.ldc + nw0 + c4 * 4);
+                rl[it] = *reinterpret_cast<const f16x4 *>(G.res_lo + row * G.ldc + nw0 + c4 * 4);
+                mean[it] = G.res_stats[2 * row];
+                rstd[it] = G.res_stats[2 * row + 1];
+            }
+            epi_sync<WAVE_SYNC>();
+#pragma unroll
+            for (int x = 0; x < 2; ++x)
+#pragma unroll
+                for (int rq = 0; rq < 4; ++rq) {
+                    const f32x16 &a = acc[x][y];
+                    *reinterpret_cast<f32x4 *>(slab + i * LS + x * 32 + 8 * rq + 4 * g) =
+                        f32x4{a[4 * rq], a[4 * rq + 1], a[4 * rq + 2], a[4 * rq + 3]};
+                }
+            epi_sync<WAVE_SYNC>();
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int rr = it * 4 + (l >> 4);
+                const size_t row = (size_t)(mw0 + y * 32 + rr);
+                f32x4 x32;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) x32[e] = (float)rh[it][e] + (float)rl[it][e];
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(slab + rr * LS + c4 * 4) + bias +
+                                ln_apply4(x32, mean[it], rstd[it], lng, lnb);
+                const f16x4 hi = f16x4{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+                const f16x4 lo = f16x4{(_Float16)(v[0] - (float)hi[0]), (_Float16)(v[1] - (float)hi[1]),
+                                       (_Float16)(v[2] - (float)hi[2]), (_Float16)(v[3] - (float)hi[3])};
+                *reinterpret_cast<f16x4 *>(G.out16 + row * G.ldc + nw0 + c4 * 4) = hi;
+                *reinterpret_cast<f16x4 *>(G.out_lo + row * G.ldc + nw0 + c4 * 4) = lo;
+                const float m64 = row16_sum((v[0] + v[1]) + (v[2] + v[3])) * (1.0f / 64.0f);
+                const float d0 = v[0] - m64, d1 = v[1] - m64, d2 = v[2] - m64, d3 = v[3] - m64;
+                const float q64 = row16_sum((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3));
+                if (c4 == 0) {
+                    float *pp = G.part + (row * n_parts + slice) * 2;
+                    pp[0] = m64;
+                    pp[1] = q64;
+                }
+            }
+        }
     } else {
         // fp16 outputs: slab [64 m][64 n] halves, row stride 72 halves (144 B); 2 passes
         _Float16 *slab = smem + w * 8192;  // 16 KiB per wave
@@ -158,7 +240,13 @@ __device__ __forceinline__ void gemm256_epilogue(const GemmArgs &G, f32x16 (&acc
         for (int p = 0; p < 2; ++p) {
             epi_sync<WAVE_SYNC>();
 #pragma unroll
-            for (int yy = 0; yy < 2; ++yy)
+            for (int yy = 0; yy < 2; ++yy) {
+                float mu = 0.f, rs = 1.f;
+                if constexpr (FOLD) {  // tokens are the rows: one (mean, rstd) per lane and 32-row block
+                    const float *sp = G.row_stats + 2 * (size_t)(mw0 + (2 * p + yy) * 32 + i);
+                    mu = sp[0];
+                    rs = sp[1];
+                }
 #pragma unroll
                 for (int x = 0; x < 2; ++x)
 #pragma unroll
@@ -166,7 +254,12 @@ __device__ __forceinline__ void gemm256_epilogue(const GemmArgs &G, f32x16 (&acc
                         const f32x16 &a = acc[x][2 * p + yy];
                         const int nl = x * 32 + 8 * rq + 4 * g;  // local n of element 0
                         const f32x4 bias = *reinterpret_cast<const f32x4 *>(G.bias + nw0 + nl);
-                        f32x4 t = f32x4{a[4 * rq], a[4 * rq + 1], a[4 * rq + 2], a[4 * rq + 3]} + bias;
+                        f32x4 t = f32x4{a[4 * rq], a[4 * rq + 1], a[4 * rq + 2], a[4 * rq + 3]};
+                        if constexpr (FOLD) {
+                            const f32x4 cs = *reinterpret_cast<const f32x4 *>(G.csum + nw0 + nl);
+                            t = (t - mu * cs) * rs;
+                        }
+                        t = t + bias;
                         if constexpr (EPI == EPI_GELU) {
                             t = gelu_erf256(t);
                         } else {
@@ -176,6 +269,7 @@ __device__ __forceinline__ void gemm256_epilogue(const GemmArgs &G, f32x16 (&acc
                         const f16x4 v = f16x4{(_Float16)t[0], (_Float16)t[1], (_Float16)t[2], (_Float16)t[3]};
                         *reinterpret_cast<f16x4 *>(slab + (yy * 32 + i) * LS + nl) = v;
                     }
+            }
             epi_sync<WAVE_SYNC>();
             // read back: 8 lanes cover one row (64 halves = 128 B), 8 rows per instruction
             const int c8 = l & 7;

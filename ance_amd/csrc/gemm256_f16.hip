@@ -269,15 +269,23 @@ int launch256(int epi, const GemmArgs &G, hipStream_t st) {
         case EPI_GELU: k = desc ? gemm256_f16_desc_kernel<EPI_GELU> : gemm256_f16_kernel<EPI_GELU, ABLATE>; break;
         case EPI_RES32: k = desc ? gemm256_f16_desc_kernel<EPI_RES32> : gemm256_f16_kernel<EPI_RES32, ABLATE>; break;
         case EPI_VT: k = desc ? gemm256_f16_desc_kernel<EPI_VT> : gemm256_f16_kernel<EPI_VT, ABLATE>; break;
+        case EPI_RESLN: k = gemm256_f16_desc_kernel<EPI_RESLN>; break;
+        case EPI_QK_F: k = gemm256_f16_desc_kernel<EPI_QK_F>; break;
+        case EPI_GELU_F: k = gemm256_f16_desc_kernel<EPI_GELU_F>; break;
+        case EPI_VT_F: k = gemm256_f16_desc_kernel<EPI_VT_F>; break;
         default: set_last_error("gemm256: bad epilogue"); return ANCE_E_INVALID;
     }
-    static bool attr_done[8] = {false, false, false, false, false, false, false, false};  // per template instance
-    const int ai = epi + (desc ? 4 : 0);
-    if (!attr_done[ai]) {
+    // the dynamic-LDS attribute is per template instance AND per device
+    static unsigned long long attr_done[2 * EPI_COUNT] = {0};
+    const int ai = epi + ((desc || epi >= EPI_RESLN) ? EPI_COUNT : 0);
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const unsigned long long dbit = 1ull << (dev & 63);
+    if (!(attr_done[ai] & dbit)) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)G256_LDS_BYTES) != hipSuccess)
             return check_launch("gemm256 attr");
-        attr_done[ai] = true;
+        attr_done[ai] |= dbit;
     }
     hipLaunchKernelGGL(k, dim3(blocks), dim3(G256_THREADS), G256_LDS_BYTES, st, G);
     return ANCE_OK;

@@ -4,7 +4,11 @@
 
 namespace ance {
 
-enum { EPI_QK = 0, EPI_GELU = 1, EPI_RES32 = 2, EPI_VT = 3 };
+// EPI_*_F: the A-side LayerNorm is folded into the GEMM (encoder.hip, "LayerNorm without a kernel"): the token operand is
+// fp16 of the PRE-LayerNorm row, the weight is fp16(gamma (.) W), and the epilogue finishes  r (acc - mu c) + b'  with the
+// per-token (mu, r) = row_stats and the per-feature c = csum.  EPI_RESLN: EPI_RES32 with the residual stream kept as an
+// fp16 (hi, lo) pair and the per-row statistics of its OUTPUT left as partial (mean, M2) of every 64-column slice.
+enum { EPI_QK = 0, EPI_GELU = 1, EPI_RES32 = 2, EPI_VT = 3, EPI_RESLN = 4, EPI_QK_F = 5, EPI_GELU_F = 6, EPI_VT_F = 7, EPI_COUNT = 8 };
 
 struct GemmArgs {
     const _Float16 *A;  // [M, K], row stride lda (halves)
@@ -24,6 +28,15 @@ struct GemmArgs {
     int scale_cols;
     const int *col_map;  // EPI_VT: token n -> destination column
     int n_valid;         // EPI_VT: columns n >= n_valid are not stored
+    // folded LayerNorm (EPI_*_F): token statistics (mean, rstd) -- tokens are the rows m (QK_F / GELU_F) or the columns n
+    // (VT_F) -- and the per-feature sum of the folded fp16 weight row
+    const float *row_stats;
+    const float *csum;
+    // EPI_RESLN: residual = LayerNorm(res_hi + res_lo) with res_stats / res_gamma / res_beta; outputs out16 (hi), out_lo
+    // and part[m][N / 64][2] = (mean, M2) of the 64 output columns each wave owns
+    const _Float16 *res_hi, *res_lo;
+    _Float16 *out_lo;
+    float *part;
     int debug_mode;      // ance_debug_gemm ablations: 1 = no loads after tile 0, 2 = no MFMA, 4 = all blocks load tile (0,0)
 };
 

@@ -311,14 +311,40 @@ def cpu_search_baseline(n_rows_total, k, seconds):
                        % (done, n_s, k, n_rows_total))
 
 
+def launch_ranks(a):
+    """`python bench.py --gpus N` without a launcher: start N ranks (one per GPU, RCCL) under torch.distributed.run --
+    the reference's own launch is `python -m torch.distributed.launch --nproc_per_node=N` (commands/run_ann_data_gen.sh:44-49,
+    drivers/run_ann_data_gen.py:637-640).  Refuses to measure fewer GPUs than were asked for."""
+    import subprocess
+    import torch
+    have = torch.cuda.device_count()
+    if a.gpus > have and os.environ.get("ANCE_BENCH_BACKEND", "nccl") == "nccl":
+        sys.stderr.write("bench.py: --gpus %d but this node has %d visible GPU(s); RCCL needs one device per rank\n" % (a.gpus, have))
+        sys.exit(2)
+    port = os.environ.get("MASTER_PORT", str(29500 + os.getpid() % 2000))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    sys.exit(subprocess.call(cmd, env=env))
+
+
 def main():
     a = parse()
+    if a.gpus < 1:
+        sys.stderr.write("bench.py: --gpus must be >= 1\n")
+        sys.exit(2)
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        return launch_ranks(a)
     if a.full:
         return full_refresh(a)
     import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE is %d: the launcher must start one rank per GPU\n" % (a.gpus, world))
+        sys.exit(2)
     dist_on = world > 1
     # one rank per GPU; ANCE_BENCH_BACKEND=gloo lets two ranks share a GPU to exercise the N > 1 code path on a
     # one-GPU box (RCCL refuses duplicate devices) -- a functional check, not a measurement
@@ -339,6 +365,8 @@ def main():
     eng = adg.HipEngine(dev)
     errors = {}
     out = {"metric": "passages_encoded_per_sec", "value": None, "unit": "passages/s", "n_gpus": world,
+           "rccl_ranks": (torch.distributed.get_world_size() if dist_on else 1),
+           "backend": (torch.distributed.get_backend() if dist_on else None),
            "steps": a.steps, "warmup": a.warmup, "ms_per_step": None, "higher_is_better": True, "scaling": "weak",
            "vs_baseline": None, "dtype": "f16", "data": "synthetic",
            "config": {"workload": "MS MARCO passage %d x 768-d, roberta-base rdot_nll FirstP seq_len=%d, encode + "

@@ -35,3 +35,22 @@ def test_bench_records_match_cache_layout():
     rec, lens = bench.synthetic_records(rng, 64, 32)
     assert rec.shape == (64, 33) and rec.dtype == np.int32
     assert np.array_equal(rec[:, 0].view(">u4").astype(np.int64).reshape(-1), lens.astype(np.int64))  # big-endian header
+
+
+def test_gpus_flag_refuses_to_measure_fewer_devices(tmp_path):
+    """`bench.py --gpus N` starts N ranks itself; with fewer visible GPUs than ranks it must fail loudly instead of
+    printing a one-rank line (the flag used to be parsed and never read)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    env["HIP_VISIBLE_DEVICES"] = ""
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 2 and "visible GPU" in r.stderr and r.stdout.strip() == ""
+    # a launcher that started a different number of ranks than --gpus says is refused as well
+    env["WORLD_SIZE"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4"], capture_output=True, text=True, env=env,
+                       timeout=300)
+    assert r.returncode == 2 and "WORLD_SIZE" in r.stderr

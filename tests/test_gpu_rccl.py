@@ -1,0 +1,62 @@
+"""RCCL on real devices (skipped only on a box with fewer than two GPUs): the collectives of the N > 1 refresh --
+query all-gather, per-shard search with row_base, all-to-all by query owner, merge, gather on rank 0
+(ance_amd/ann_data_gen.py: Dist, sharded_search; reference: drivers/run_ann_data_gen.py:637-640 init_process_group("nccl"),
+utils/util.py:barrier_array_merge) -- on device tensors over backend "nccl".  The merged lists must be bit-identical to one
+rank searching the whole corpus."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _rank(rank, world, port, out_path):
+    sys.path.insert(0, ROOT)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    from ance_amd import ann_data_gen as adg
+    from ance_amd.cache import shard_range
+    from oracle import synth
+    torch.cuda.set_device(rank)
+    dev = torch.device("cuda", rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    rng = np.random.default_rng(3)
+    n, nq, k = 30011, 257, 100
+    x = synth.ln_rows(rng, n)
+    q = synth.ln_rows(rng, nq)
+    d = adg.Dist()
+    assert d.world == world and d.rank == rank and dist.get_backend() == "nccl"
+    eng = adg.HipEngine(dev)
+    r0, r1 = shard_range(n, rank, world)
+    # every rank holds only its query block before the gather, like the encode phase leaves them
+    q0, q1 = shard_range(nq, rank, world)
+    q_all = adg.gather_queries(d, torch.from_numpy(q[q0:q1]).to(dev), nq)
+    assert torch.equal(q_all.cpu(), torch.from_numpy(q))
+    res = adg.sharded_search(eng, d, torch.from_numpy(x[r0:r1]).to(dev), r0, q_all, k)
+    if rank == 0:
+        D, I = res
+        np.savez(out_path, D=D.cpu().numpy(), I=I.cpu().numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL needs one device per rank: fewer than 2 GPUs on this box")
+def test_sharded_search_over_rccl(tmp_path):
+    from oracle import search_ref, synth
+    world = min(torch.cuda.device_count(), 4)
+    out = str(tmp_path / "merged.npz")
+    port = 29700 + os.getpid() % 2000
+    torch.multiprocessing.spawn(_rank, args=(world, port, out), nprocs=world, join=True)
+    got = np.load(out)
+    rng = np.random.default_rng(3)
+    x = synth.ln_rows(rng, 30011)
+    q = synth.ln_rows(rng, 257)
+    Do, Io = search_ref.flat_ip_topk_chain(x, q, 100)
+    assert np.array_equal(got["I"], Io) and np.array_equal(got["D"], Do)

@@ -1,0 +1,137 @@
+"""CPU model of the encoder's rounding points (csrc/encoder.hip): fp16 MFMA operands, fp32 everything else.
+
+Two schemes are restated in torch and compared with the fp32 oracle on the same random-init 12-layer model:
+  * "plain": the token operand of every GEMM is fp16(LayerNorm(v)), weights fp16(W), fp32 residual stream;
+  * "fold" (the default of the library): token operand fp16(v) of the PRE-LayerNorm row, weights fp16(gamma (.) W),
+    epilogue r (acc - mu c) + (b + W beta) with c summed over the rounded weights, residual stream kept as an fp16
+    (hi, lo) pair, row statistics combined from the (mean, M2) of 64-column slices (Chan).
+The model checks the ALGEBRA of the fold (it must agree with the oracle to fp16-operand accuracy, not just roughly) and
+that the fold does not cost accuracy against the plain scheme.  The HIP kernels themselves are tested on the GPU
+(tests/test_gpu_encoder.py)."""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from oracle import encoder_ref, synth
+
+
+def h16(x):
+    return x.to(torch.float16).to(torch.float32)
+
+
+def stats_from_slices(v, eps):
+    """(mean, rstd) of the rows of v [T, 768] from per-64-column (mean, M2), as EPI_RESLN + ln_finalize_kernel."""
+    T, H = v.shape
+    s = v.reshape(T, H // 64, 64)
+    m_i = s.mean(-1)
+    q_i = ((s - m_i[..., None]) ** 2).sum(-1)
+    m = m_i.mean(-1)
+    q = (q_i + 64.0 * (m_i - m[:, None]) ** 2).sum(-1)
+    return m, torch.rsqrt(q / H + eps)
+
+
+def folded_linear(x_hi, mu, r, W, b, gamma, beta):
+    W16 = h16(gamma[None, :] * W)
+    c = W16.sum(1)
+    bf = b + W @ beta
+    acc = x_hi @ W16.t()
+    return r[:, None] * (acc - mu[:, None] * c[None, :]) + bf[None, :]
+
+
+def attention(q, k, v, lens, n_heads=12):
+    out = torch.zeros_like(q)
+    off = 0
+    for T in lens:
+        for h in range(n_heads):
+            sl = slice(h * 64, h * 64 + 64)
+            s = q[off:off + T, sl] @ k[off:off + T, sl].t()  # q carries log2(e)/8
+            p = torch.exp2(s - s.max(1, keepdim=True).values)
+            out[off:off + T, sl] = (h16(p) @ v[off:off + T, sl]) / p.sum(1, keepdim=True)
+        off += T
+    return out
+
+
+def run(sd, ids, lens, n_layers, fold, eps=1e-5):
+    pre = "roberta."
+    e = pre + "embeddings."
+    rows, pos = [], []
+    for s, T in enumerate(lens):
+        rows.append(ids[s, :T])
+        pos.append(torch.arange(T) + 2)
+    tok, p = torch.cat(rows).long(), torch.cat(pos)
+    v = (sd[e + "word_embeddings.weight"][tok] + sd[e + "token_type_embeddings.weight"][0]) + sd[e + "position_embeddings.weight"][p]
+    g_in, b_in = sd[e + "LayerNorm.weight"], sd[e + "LayerNorm.bias"]
+    qscale = 0.125 * math.log2(math.e)
+
+    def split(v):
+        hi = h16(v)
+        return hi, h16(v - hi)
+
+    def ln_rows(x, mu, r, g, b):
+        return (x - mu[:, None]) * r[:, None] * g[None, :] + b[None, :]
+
+    if fold:
+        hi, lo = split(v)
+        mu, r = v.mean(1), torch.rsqrt(v.var(1, unbiased=False) + eps)
+    for i in range(n_layers):
+        L = "%sencoder.layer.%d." % (pre, i)
+        W = lambda n: sd[L + n + ".weight"]
+        B = lambda n: sd[L + n + ".bias"]
+        if fold:
+            q = h16(folded_linear(hi, mu, r, W("attention.self.query"), B("attention.self.query"), g_in, b_in) * qscale)
+            k = h16(folded_linear(hi, mu, r, W("attention.self.key"), B("attention.self.key"), g_in, b_in))
+            vv = h16(folded_linear(hi, mu, r, W("attention.self.value"), B("attention.self.value"), g_in, b_in))
+            res = ln_rows(hi + lo, mu, r, g_in, b_in)
+        else:
+            x = F.layer_norm(v, (768,), g_in, b_in, eps)
+            x16 = h16(x)
+            q = h16((x16 @ h16(W("attention.self.query")).t() + B("attention.self.query")) * qscale)
+            k = h16(x16 @ h16(W("attention.self.key")).t() + B("attention.self.key"))
+            vv = h16(x16 @ h16(W("attention.self.value")).t() + B("attention.self.value"))
+            res = x
+        ctx = h16(attention(q, k, vv, lens))
+        va = ctx @ h16(W("attention.output.dense")).t() + B("attention.output.dense") + res
+        g1, b1 = sd[L + "attention.output.LayerNorm.weight"], sd[L + "attention.output.LayerNorm.bias"]
+        if fold:
+            hia, loa = split(va)
+            mua, ra = stats_from_slices(va, eps)
+            f = h16(F.gelu(folded_linear(hia, mua, ra, W("intermediate.dense"), B("intermediate.dense"), g1, b1)))
+            resa = ln_rows(hia + loa, mua, ra, g1, b1)
+        else:
+            xa = F.layer_norm(va, (768,), g1, b1, eps)
+            f = h16(F.gelu(h16(xa) @ h16(W("intermediate.dense")).t() + B("intermediate.dense")))
+            resa = xa
+        v = f @ h16(W("output.dense")).t() + B("output.dense") + resa
+        g_in, b_in = sd[L + "output.LayerNorm.weight"], sd[L + "output.LayerNorm.bias"]
+        if fold:
+            hi, lo = split(v)
+            mu, r = stats_from_slices(v, eps)
+    if fold:
+        x = ln_rows(hi + lo, mu, r, g_in, b_in)
+    else:
+        x = F.layer_norm(v, (768,), g_in, b_in, eps)
+    first = np.concatenate([[0], np.cumsum(lens)[:-1]])
+    cls = x[torch.as_tensor(first)]
+    z = F.linear(cls, sd["embeddingHead.weight"], sd["embeddingHead.bias"])
+    return F.layer_norm(z, (768,), sd["norm.weight"], sd["norm.bias"], 1e-5)
+
+
+def test_fold_matches_oracle_as_well_as_the_plain_scheme():
+    torch.manual_seed(0)
+    n_layers = 12
+    sd = encoder_ref.random_state_dict(seed=5, n_layers=n_layers, ln_jitter=0.1)
+    rng = np.random.default_rng(8)
+    lens = np.array([1, 2, 31, 33, 64, 65, 96, 128, 70, 9, 100, 50], dtype=np.int64)
+    ids = torch.from_numpy(synth.make_records(rng, len(lens), 128, lens))
+    with torch.no_grad():
+        want = encoder_ref.rdot_nll_ln_emb(sd, ids, encoder_ref.mask_from_lengths(lens, 128), n_layers=n_layers)
+        plain = run(sd, ids, lens, n_layers, fold=False)
+        fold = run(sd, ids, lens, n_layers, fold=True)
+    e_plain = float((plain - want).abs().max())
+    e_fold = float((fold - want).abs().max())
+    print("max |delta| vs fp32 oracle: plain %.3e  fold %.3e" % (e_plain, e_fold))
+    assert e_plain < 5e-3
+    assert e_fold < 5e-3
+    assert e_fold < 1.5 * e_plain + 5e-4
