@@ -8,7 +8,8 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libance_amd.so")
+# ANCE_AMD_LIB: another build of the same ABI (the measurement library of `make -C ance_amd/csrc measure`)
+LIB_PATH = os.environ.get("ANCE_AMD_LIB") or os.path.join(_HERE, "libance_amd.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 ANCE_OK = 0
@@ -72,6 +73,7 @@ SYMBOLS = {
     "ance_host_write_ann_training": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
                                                     ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                                     ctypes.c_int, ctypes.POINTER(ctypes.c_int64)]),
+    "ance_reload_env": (None, []),
     "ance_debug_search_stamps": (None, [ctypes.c_void_p]),
     "ance_debug_gemm": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
                                        ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
@@ -125,6 +127,11 @@ def lib():
         raise AnceLibraryError("ABI version mismatch: library %d, binding %d" % (L.ance_abi_version(), ABI_VERSION))
     _lib = L
     return L
+
+
+def reload_env():
+    """The library reads its ANCE_* knobs once; call this after changing one inside a running process."""
+    lib().ance_reload_env()
 
 
 def check(rc, what):

@@ -198,11 +198,18 @@ __global__ void __launch_bounds__(ATT_THREADS, 4) attention_kernel(const AttnArg
 // 16-byte load of a key-contiguous V^T row instead of two 8-byte pieces.
 __device__ __forceinline__ int key_perm(int i) { return (i & ~12) | ((i & 4) << 1) | ((i & 8) >> 1); }
 
+// One instruction; an fmaxf chain gets a canonicalising v_max in front of every MFMA output.  hipcc does not pad the
+// MFMA-result -> VALU-read hazard for an instruction inside an asm statement: the caller puts mfma_result_pad() between
+// the last MFMA that wrote the operands and the first max3f that reads them (without it the maximum is read from
+// registers the matrix pipe has not written yet -- on some waves, on some launches).
 __device__ __forceinline__ float max3f(float a, float b, float c) {
-    float r;  // one instruction; fmaxf chains get a canonicalising v_max in front of every MFMA output
-    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    float r;
+    asm volatile("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
     return r;
 }
+// 12 wait states (8-pass XDL result -> any reader), tied to the accumulator by a read-write operand: the statement cannot
+// move above the MFMA that produces it, and no reader of it can move above the statement.
+__device__ __forceinline__ void mfma_result_pad(f32x16 &acc) { asm volatile("s_nop 11" : "+v"(acc)); }
 
 template <int N>
 __device__ __forceinline__ void attend_reg(const AttnArgs &A, int s, int h, int tok0, int T, int vcol0, int l) {
@@ -273,6 +280,7 @@ __device__ __forceinline__ void attend_reg(const AttnArgs &A, int s, int h, int 
                     st[r] = key < T ? st[r] : -INFINITY;
                 }
             }
+            mfma_result_pad(st);
             float bm = max3f(st[0], st[1], st[2]);
 #pragma unroll
             for (int r = 3; r < 15; r += 2) bm = max3f(bm, st[r], st[r + 1]);

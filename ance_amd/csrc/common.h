@@ -58,4 +58,16 @@ __device__ inline int lane_id() { return (int)(threadIdx.x & 63); }
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// hipFuncSetAttribute is per device: one bit per device ordinal (ordinals above 62: set every time).  Returns true when
+// the caller has to set its attributes for the current device.
+inline bool attr_needed(unsigned long long *done) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 63) return true;
+    const unsigned long long bit = 1ull << dev;
+    if (*done & bit) return false;
+    *done |= bit;
+    return true;
+}
+
 }  // namespace ance

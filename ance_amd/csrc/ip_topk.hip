@@ -273,12 +273,11 @@ int launch_finalize_keys(const u64 *keys, int64_t nq, int m, int k, int64_t row_
         set_last_error("topk_finalize: more than 8192 survivors per query");
         return ANCE_E_INVALID;
     }
-    static int attr_p2 = 0;
-    if (P2 > attr_p2) {
+    static unsigned long long attr_done = 0;  // per device, for the largest list this kernel takes
+    if (attr_needed(&attr_done)) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(topk_finalize_kernel<false>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)(P2 * sizeof(u64))) != hipSuccess)
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)(8192 * sizeof(u64))) != hipSuccess)
             return check_launch("topk_finalize attr");
-        attr_p2 = P2;
     }
     ProfScope pf(PC_FINALIZE, st);
     hipLaunchKernelGGL(topk_finalize_kernel<false>, dim3((unsigned)nq), dim3(256), P2 * sizeof(u64), st, keys,
@@ -292,12 +291,11 @@ int launch_reduce_keys(const u64 *keys, int nq_max, int m, int k, u64 *out, cons
         set_last_error("topk_reduce_keys: more than 8192 keys per query");
         return ANCE_E_INVALID;
     }
-    static int attr_p2 = 0;
-    if (P2 > attr_p2) {
+    static unsigned long long attr_done = 0;
+    if (attr_needed(&attr_done)) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(topk_reduce_keys_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)(P2 * sizeof(u64))) != hipSuccess)
+                                (int)(8192 * sizeof(u64))) != hipSuccess)
             return check_launch("topk_reduce_keys attr");
-        attr_p2 = P2;
     }
     hipLaunchKernelGGL(topk_reduce_keys_kernel, dim3((unsigned)nq_max), dim3(256), P2 * sizeof(u64), st, keys, m, P2, k, out, nq_dev);
     return ANCE_OK;
@@ -307,13 +305,12 @@ namespace {
 int launch_scan(const Plan &pl, const float *d_x, int64_t n, const float *q, int64_t nqc, int d, int k, u64 *cand, u64 *part,
                 const int *only_if, const int *nq_dev, hipStream_t st) {
     auto scan = pl.npl == 8 ? ip_topk_scan_kernel<8> : (pl.npl == 16 ? ip_topk_scan_kernel<16> : ip_topk_scan_kernel<32>);
-    static bool attr_done[3] = {false, false, false};
+    static unsigned long long attr_done[3] = {0, 0, 0};
     const int ai = pl.npl == 8 ? 0 : (pl.npl == 16 ? 1 : 2);
-    if (!attr_done[ai]) {
+    if (attr_needed(&attr_done[ai])) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(scan), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)SCAN_LDS_BYTES) != hipSuccess)
             return check_launch("ip_topk_scan attr");
-        attr_done[ai] = true;
     }
     ScanParams P;
     P.x = d_x; P.q = q; P.n = (uint32_t)n; P.nq = (uint32_t)nqc; P.d = d; P.k = k; P.S = pl.S;
@@ -365,15 +362,25 @@ size_t ip_topk_fast_workspace_bytes(int64_t n, int64_t nq, int d, int k, bool wi
 int ip_topk_fast(const float *d_x, int64_t n, int64_t row_base, const void *d_index, const float *d_q, int64_t nq, int d, int k,
                  float *d_out_d, int64_t *d_out_i, void *d_workspace, size_t workspace_bytes, hipStream_t st);
 void set_fast_stamps(unsigned long long *d_stamps);
+void reload_fast_knobs();
 }
 
 extern "C" void ance_debug_search_stamps(void *d_stamps) { ance::set_fast_stamps(reinterpret_cast<unsigned long long *>(d_stamps)); }
 
 // ANCE_SEARCH=exact forces the fp32-MFMA scan everywhere (A/B and cross-checks); default: the
 // two-precision path whenever the shape is eligible (d % 128 == 0, d <= 2048, k <= 1024, n >= 4096).
+static int g_search_exact = -1;  // ANCE_SEARCH, read once (ance_reload_env re-reads)
 static bool fast_enabled() {
-    const char *e = getenv("ANCE_SEARCH");
-    return !(e && !strcmp(e, "exact"));
+    if (g_search_exact < 0) {
+        const char *e = getenv("ANCE_SEARCH");
+        g_search_exact = (e && !strcmp(e, "exact")) ? 1 : 0;
+    }
+    return g_search_exact == 0;
+}
+
+extern "C" void ance_reload_env(void) {
+    g_search_exact = -1;
+    ance::reload_fast_knobs();
 }
 
 static size_t scan_workspace_bytes(int64_t n, int64_t nq, int k) {

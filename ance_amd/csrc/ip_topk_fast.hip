@@ -1076,6 +1076,33 @@ int env_int(const char *name, int dflt) {
     return e && *e ? atoi(e) : dflt;
 }
 
+// Tuning knobs of the fast path (include/ance_amd.h lists them): read from the environment ONCE, when the library first
+// needs them; ance_reload_env() re-reads (tests and sweeps that change a knob inside one process call it).
+struct FastKnobs {
+    int splits, window_tiles, dedup, center, share, wait_us, prune_at, prune_growth, debug;
+    void load() {
+        splits = env_int("ANCE_FAST_SPLITS", 0);
+        window_tiles = env_int("ANCE_FAST_WINDOW_TILES", 256);
+        dedup = env_int("ANCE_FAST_DEDUP", 1) != 0;
+        center = env_int("ANCE_FAST_CENTER", 1) != 0;
+        share = env_int("ANCE_FAST_SHARE", 1);
+        wait_us = env_int("ANCE_FAST_WINDOW_WAIT_US", 200);
+        prune_at = env_int("ANCE_FAST_PRUNE_AT", 512);
+        prune_growth = env_int("ANCE_FAST_PRUNE_GROWTH", 150);
+        if (prune_growth < 105) prune_growth = 105;
+        debug = env_int("ANCE_FAST_DEBUG", 0);
+    }
+};
+FastKnobs &fast_knobs() {
+    static FastKnobs k = [] {
+        FastKnobs x;
+        x.load();
+        return x;
+    }();
+    return k;
+}
+
+
 bool fast_shape_ok(int64_t n, int d, int k) {
     return d >= 128 && d % 128 == 0 && d <= F_MAX_D && k >= 1 && k <= F_MAX_K && n >= 4096 && n < (1ll << 32);
 }
@@ -1086,7 +1113,7 @@ bool make_fast_plan(int64_t n, int64_t nq, int d, int k, FastPlan *pl) {
     const int64_t nqt = (nq + FQ - 1) / FQ;
     // One workgroup per CU: (query tiles per launch) x (corpus splits) = 256.  More splits = fewer query tiles per
     // XCD (better L2 reuse of the query side) but one more candidate list per query; ANCE_FAST_SPLITS overrides.
-    int S = env_int("ANCE_FAST_SPLITS", 0);
+    int S = fast_knobs().splits;
     if (S < 1 || S > 32 || (S & (S - 1))) S = 2;
     while (nqt * S < 256 && S < 32) S <<= 1;
     while (S > 1 && (S * 8 > n_tiles || next_pow2((S + DEDUP_MAXC) * k) > 8192)) S >>= 1;
@@ -1095,7 +1122,7 @@ bool make_fast_plan(int64_t n, int64_t nq, int d, int k, FastPlan *pl) {
     pl->qc = qct * FQ;
     // window: ANCE_FAST_WINDOW_TILES corpus tiles of 256 rows (default 256 = 100 MB of fp16 rows at d = 768; 0 = one
     // window, i.e. every split scans its contiguous share as the first version of this kernel did)
-    int Wt = env_int("ANCE_FAST_WINDOW_TILES", 256);
+    int Wt = fast_knobs().window_tiles;
     if (Wt <= 0 || Wt > n_tiles) Wt = n_tiles;
     pl->Ws = (Wt + S - 1) / S;
     pl->q2_bytes = align_up((size_t)pl->qc * d * sizeof(_Float16), 256);
@@ -1126,7 +1153,8 @@ unsigned long long *g_fast_stamps = nullptr;
 
 // measurement hook: while d_stamps != NULL the filter kernel is the instrumented build and every workgroup of the LAST launch
 // chunk leaves uint64[8] = {prologue, main loop, filter, prune, sync, block end} ticks of the 100 MHz counter, (qt << 32 | split), XCC id
-void set_fast_stamps(unsigned long long *d_stamps) { g_fast_stamps = d_stamps; }
+void set_fast_stamps(unsigned long long *d_stamps) { g_fast_stamps = d_stamps; }  // read by ANCE_MEASURE builds only
+void reload_fast_knobs() { fast_knobs().load(); }
 
 // ---- search image --------------------------------------------------------------------------------------
 size_t ip_index_bytes(int64_t n, int d) {
@@ -1154,8 +1182,8 @@ int ip_index_build(const float *d_x, int64_t n, int d, void *d_index, size_t ind
     u64 *samp = reinterpret_cast<u64 *>(base + L.samp_off);
     float *mu = reinterpret_cast<float *>(base + L.mu_off);
     float *part = reinterpret_cast<float *>(base + L.part_off);
-    const bool dedup = env_int("ANCE_FAST_DEDUP", 1) != 0;
-    const int center = env_int("ANCE_FAST_CENTER", 1) != 0;
+    const bool dedup = fast_knobs().dedup != 0;
+    const int center = fast_knobs().center;
     ProfScope ps(PC_PLAN, st);
     (void)hipMemsetAsync(H, 0, 256, st);
     hipLaunchKernelGGL(idx_colsum_kernel, dim3((unsigned)L.n_part), dim3(256), 0, st, d_x, n, d, part);
@@ -1227,20 +1255,21 @@ int ip_topk_fast(const float *d_x, int64_t n, int64_t row_base, const void *d_in
     int *ovf_flag = reinterpret_cast<int *>(zero_area + 256);
     int *ovf_list = ovf_flag + pl.qc;
 
-    static bool attr_done = false;
-    if (!attr_done) {
+    static unsigned long long attr_done = 0;
+    if (attr_needed(&attr_done)) {
         bool ok = true;
         for (const void *fn : {reinterpret_cast<const void *>(ip_topk_fast_kernel<false, false>),
-                               reinterpret_cast<const void *>(ip_topk_fast_kernel<false, true>),
+#ifdef ANCE_MEASURE
                                reinterpret_cast<const void *>(ip_topk_fast_kernel<true, false>),
-                               reinterpret_cast<const void *>(ip_topk_fast_kernel<true, true>)})
+                               reinterpret_cast<const void *>(ip_topk_fast_kernel<true, true>),
+#endif
+                               reinterpret_cast<const void *>(ip_topk_fast_kernel<false, true>)})
             ok = ok && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)F_LDS_BYTES) == hipSuccess;
         if (!ok)
             return check_launch("ip_topk_fast attr");
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(rescore_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)rescore_lds_bytes(F_MAX_D)) != hipSuccess)
             return check_launch("rescore attr");
-        attr_done = true;
     }
     EpsConst eps;
     eps.rel_c = 1.25f * (9.765625e-4f + 1.1f * d * 5.9604645e-8f);
@@ -1256,19 +1285,18 @@ int ip_topk_fast(const float *d_x, int64_t n, int64_t row_base, const void *d_in
         ProfScope ps(PC_PLAN, st);
         hipLaunchKernelGGL(idx_colsum_kernel, dim3((unsigned)n_part_q), dim3(256), 0, st, d_q, nq, d, qpart);
         hipLaunchKernelGGL(idx_mean_kernel, dim3((unsigned)((d + 255) / 256)), dim3(256), 0, st, qpart, n_part_q, nq, d,
-                           env_int("ANCE_FAST_CENTER", 1) != 0, mq);
+                           fast_knobs().center, mq);
         hipLaunchKernelGGL(query_mean_decide_kernel, dim3(1), dim3(256), 0, st, mq, d, reinterpret_cast<const DedupHeader *>(ib), qstat);
         (void)hipMemsetAsync(bias, 0, pl.bias_bytes, st);
         hipLaunchKernelGGL(row_bias_kernel, dim3(4096), dim3(256), 0, st, d_x, d, reinterpret_cast<const DedupHeader *>(ib),
                            reinterpret_cast<const uint32_t *>(ib + Li.live_off), reinterpret_cast<const float *>(ib + Li.mu_off), mq,
                            qstat, bias);
     }
-    const int share = env_int("ANCE_FAST_SHARE", 1);
-    const int wait_us = env_int("ANCE_FAST_WINDOW_WAIT_US", 200);
-    const int prune_at = env_int("ANCE_FAST_PRUNE_AT", 512);
-    int prune_growth = env_int("ANCE_FAST_PRUNE_GROWTH", 150);
-    if (prune_growth < 105) prune_growth = 105;
+    const FastKnobs &kn = fast_knobs();
+    const int share = kn.share, wait_us = kn.wait_us, prune_at = kn.prune_at, prune_growth = kn.prune_growth;
+#ifdef ANCE_MEASURE
     unsigned long long *stamps = g_fast_stamps;  // measurement hook (ance_debug_search_stamps)
+#endif
     for (int64_t q0 = 0; q0 < nq; q0 += pl.qc) {
         const int64_t nqc = (nq - q0) < pl.qc ? (nq - q0) : pl.qc;
         (void)hipMemsetAsync(ff_area, 0xFF, pl.thr_bytes, st);
@@ -1289,16 +1317,23 @@ int ip_topk_fast(const float *d_x, int64_t n, int64_t row_base, const void *d_in
         P.prune_at = prune_at > k + 64 ? prune_at : k + 64;
         if (P.prune_at > F_C - FP) P.prune_at = F_C - FP;
         P.prune_growth = prune_growth;
-        P.stamps = stamps; P.dbg = env_int("ANCE_FAST_DEBUG", 0);
+#ifdef ANCE_MEASURE
+        P.stamps = stamps; P.dbg = kn.debug;
+#else
+        P.stamps = nullptr; P.dbg = 0;
+#endif
         const int gq = 32 / pl.S;
         const int groups = (P.n_qt + gq - 1) / gq;
         const unsigned blocks = (unsigned)((groups + 7) / 8 * 8) * 32u;
         {
             ProfScope ps(PC_SCAN, st, 2.0 * (double)nqc * (double)n * (double)d);
+#ifdef ANCE_MEASURE  // the instrumented builds (per-workgroup time stamps, timing experiments) exist in the measurement library only
             if (stamps) {
                 hipLaunchKernelGGL((ip_topk_fast_kernel<true, false>), dim3(blocks), dim3(F_THREADS), F_LDS_BYTES, st, P);
                 hipLaunchKernelGGL((ip_topk_fast_kernel<true, true>), dim3(blocks), dim3(F_THREADS), F_LDS_BYTES, st, P);
-            } else {
+            } else
+#endif
+            {
                 hipLaunchKernelGGL((ip_topk_fast_kernel<false, false>), dim3(blocks), dim3(F_THREADS), F_LDS_BYTES, st, P);
                 hipLaunchKernelGGL((ip_topk_fast_kernel<false, true>), dim3(blocks), dim3(F_THREADS), F_LDS_BYTES, st, P);
             }

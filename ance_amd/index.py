@@ -32,6 +32,8 @@ class FlatIPIndex:
         self._x = None
         self._ws = None
         self._image = None  # search image of self._x (device bytes), built on first use
+        self._image_key = None
+        self._image_event = None
 
     # -- faiss-like surface ---------------------------------------------------------------------
     @property
@@ -91,7 +93,15 @@ class FlatIPIndex:
         """Device buffer holding the search image of ``x`` (None when the shape has none)."""
         import torch
         n = x.shape[0]
+        # the image is a function of the rows' VALUES: rows changed in place since it was built (tensor version counter)
+        # or a different storage invalidate it -- the filter would otherwise run on stale fp16 rows while the exact
+        # re-scoring reads the new ones
+        key = (x.data_ptr(), x._version, n)
+        if self._image is not None and self._image_key != key:
+            self._image = None
         if self._image is None:
+            self._image_key = key
+            self._image_event = None
             need = L.ance_ip_index_bytes(n, self.dp) if n else 0
             if need == 0:
                 self._image = False
@@ -102,6 +112,11 @@ class FlatIPIndex:
                                                buf.numel(), _lib.current_stream_ptr())
                 _lib.check(rc, "ance_ip_index_build")
                 self._image = buf
+                # searches on another stream must not start before the build has finished
+                self._image_event = torch.cuda.Event()
+                self._image_event.record(torch.cuda.current_stream(self.device))
+        elif self._image_event is not None:
+            torch.cuda.current_stream(self.device).wait_event(self._image_event)
         return self._image if self._image is not False else None
 
     def search_device(self, qd, k):

@@ -79,7 +79,8 @@ size_t ance_ip_topk_workspace_bytes(int64_t n, int64_t nq, int d, int k);
  * A query whose candidates cannot be bounded that way (row or query norms above 65504 or NaN, i.e.
  * possible fp16 overflow; thousands of rows inside one error band) is detected on the device and
  * redone by the scan, alone; heavy classes of bit-identical rows (all-pad MaxP chunks) are scored
- * once and expanded in id order.  Environment (tuning / A-B only, read at every call):
+ * once and expanded in id order.  Environment (tuning / A-B only; read ONCE, the first time the library needs a
+ * knob -- ance_reload_env() re-reads all of them):
  *   ANCE_SEARCH=exact            force the scan
  *   ANCE_FAST_SPLITS=<2^j>       corpus splits per query tile (default 2)
  *   ANCE_FAST_WINDOW_TILES=<n>   corpus window all workgroups finish together, in 256-row tiles
@@ -220,8 +221,14 @@ int ance_encode_ids(AnceEncoder *enc, const int32_t *d_ids, int64_t ld_ids, cons
 int ance_debug_gemm(int ablate, int epi, const void *d_a_f16, const void *d_b_f16, int M, int N, int K,
                     const float *d_bias, void *d_out, const float *d_res32, void *stream);
 
+/* Re-reads every ANCE_* tuning knob from the environment (they are otherwise read once per process).  For tests and
+ * sweeps that change a knob between two calls; not thread-safe against concurrent searches. */
+void ance_reload_env(void);
+
 /*
- * Measurement hook of the two-precision search: while d_stamps != NULL, the filter kernel runs as its instrumented
+ * Measurement hook of the two-precision search -- a no-op in the product library; the instrumented kernel builds exist
+ * only in the measurement library (`make -C ance_amd/csrc measure` -> libance_amd_measure.so, -DANCE_MEASURE; load it
+ * with ANCE_AMD_LIB=<path>).  There: while d_stamps != NULL, the filter kernel runs as its instrumented
  * build and every workgroup of a launch chunk leaves uint64[8] at d_stamps + 8 * blockIdx: ticks of the 100 MHz
  * counter spent in {prologue, fp16 main loop, filter, prune, window waits, hand-over to the re-scoring kernel},
  * then (query tile << 32 | split) and the XCC id it ran on.  The buffer needs 8 * 8 * 2048 bytes.  NULL switches it off.

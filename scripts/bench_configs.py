@@ -140,6 +140,7 @@ def search_config4(torch, dev, steps, n_docs=3213835, nq=32768, k=200):
     res = {}
     for dedup in ("1", "0"):
         os.environ["ANCE_FAST_DEDUP"] = dedup
+        _lib.reload_env()
         idx = FlatIPIndex(768, device=dev)
         idx.add(x)
         torch.cuda.synchronize()
@@ -157,6 +158,7 @@ def search_config4(torch, dev, steps, n_docs=3213835, nq=32768, k=200):
         del idx
         torch.cuda.empty_cache()
     os.environ.pop("ANCE_FAST_DEDUP", None)
+    _lib.reload_env()
     same = bool(torch.equal(res["1"][2], res["0"][2]))
     I7 = res["1"][2][7].cpu().numpy()
     print(json.dumps({"config": "4: search, 12,855,340 MaxP chunk vectors", "rows": n, "all_pad_rows": int(pad_chunk.sum()),

@@ -50,6 +50,7 @@ def main():
             kv[k_] = int(v_)
         for k_, v_ in kv.items():
             os.environ[names_[k_]] = str(v_)
+        _lib.reload_env()
         D, I = idx.search_device(q, a.topk)
         torch.cuda.synchronize()
         t0 = time.perf_counter()

@@ -18,8 +18,19 @@ def _diag(name, **kw):
         json.dump({k: (v.tolist() if hasattr(v, "tolist") else v) for k, v in kw.items()}, f)
 
 
+@pytest.fixture(autouse=True)
+def _knobs_follow_the_environment():
+    """The library reads its ANCE_* knobs once per process; the tests below change them with monkeypatch.  This fixture is
+    set up before monkeypatch, so its teardown runs after the environment has been restored."""
+    yield
+    from ance_amd import _lib
+    _lib.reload_env()
+
+
 def _search(x, q, k, row_base=0):
+    from ance_amd import _lib
     from ance_amd.index import FlatIPIndex
+    _lib.reload_env()
     idx = FlatIPIndex(x.shape[1], row_base=row_base)
     idx.add(x)
     return idx.search(q, k)
