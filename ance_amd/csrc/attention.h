@@ -8,14 +8,13 @@ struct AttnArgs {
     const _Float16 *qk;    // [T, 2 H]: Q (pre-scaled by log2(e)/sqrt(64): the softmax runs on exp2) | K, row stride ld_qk
     const _Float16 *vt;    // [H, ld_vt]: V^T, row = head * 64 + dim, column = seq_vtcol[s] + key
     _Float16 *ctx;         // [T, H], row stride ld_ctx
-    const int *seq_off;    // [n_seq + 1] first token of each sequence in the packed batch
-    const int *seq_vtcol;  // [n_seq] first (8-aligned) V^T column of each sequence
+    const int4 *desc;      // per sequence, longest length bucket first: (first token, length, first (8-aligned) V^T column, sequence index)
     int ld_qk, ld_vt, ld_ctx;
     int n_heads;
     int cls_only;          // 1: only query 0 of every sequence is computed; its row goes to ctx[s] (compact)
 };
 
-size_t attention_lds_bytes(int max_seq_len);
+size_t attention_lds_bytes(int max_seq_len, int n_waves);
 int launch_attention(const AttnArgs &args, int n_seq, int max_seq_len, hipStream_t stream);
 
 }  // namespace ance

@@ -45,7 +45,7 @@ constexpr int H = 768;          // hidden size this build is specialised for
 constexpr int HEAD_OUT = 768;   // embeddingHead output (model/models.py:145)
 constexpr int S_CAP_MAX = 8192; // sequences per micro-batch
 constexpr int FETCH_CHUNK = 262144;
-constexpr int MAX_LANES = 2;     // activation sets / internal streams (a third one measured no gain: 57.6 k vs 57.7 k passages/s)
+constexpr int MAX_LANES = 4;     // activation sets / internal streams (default 2; ANCE_ENCODER_STREAMS)
 
 // ------------------------------------------------------------------------------------ kernels --
 
@@ -82,15 +82,24 @@ struct PlanArgs {
     int T, Tpad;          // real tokens / padded to 128 (host computed, same arithmetic)
     int *seq_off, *seq_vtcol, *seq_len;
     int *tok_id, *tok_pos, *tok_vtcol;
+    int4 *desc;           // attention descriptors (first token, length, V^T column, sequence), longest length bucket first
+    int bstart[4];        // first descriptor of each bucket (host computed: the host knows every length)
 };
 
-// effective lengths + exclusive scans (token offsets; 8-aligned V^T columns).  One block.
+__device__ __forceinline__ int len_bucket(int eff) {  // ceil(eff / 32) - 1, everything above 96 tokens in bucket 3
+    const int b = (eff + 31) >> 5;
+    return b > 4 ? 3 : b - 1;
+}
+
+// effective lengths + exclusive scans (token offsets; 8-aligned V^T columns; rank inside the length bucket).  One block.
 __global__ void __launch_bounds__(1024) plan_kernel(const PlanArgs P) {
     __shared__ int s_tot[1024], s_tot8[1024];
+    __shared__ unsigned long long s_bk[1024];  // four 16-bit bucket counts (a micro-batch has at most 8,192 sequences)
     const int tid = threadIdx.x;
     const int per = (P.S + 1023) / 1024;
     const int b0 = tid * per;
     int sum = 0, sum8 = 0;
+    unsigned long long bk = 0;
     for (int j = 0; j < per; ++j) {
         const int s = b0 + j;
         if (s < P.S) {
@@ -104,24 +113,30 @@ __global__ void __launch_bounds__(1024) plan_kernel(const PlanArgs P) {
             const int eff = lc > 0 ? lc : 1;
             sum += eff;
             sum8 += (eff + 7) & ~7;
+            bk += 1ull << (16 * len_bucket(eff));
         }
     }
     s_tot[tid] = sum;
     s_tot8[tid] = sum8;
+    s_bk[tid] = bk;
     __syncthreads();
     // Hillis-Steele inclusive scan over 1024 partials
     for (int off = 1; off < 1024; off <<= 1) {
         int a = 0, a8 = 0;
+        unsigned long long ab = 0;
         if (tid >= off) {
             a = s_tot[tid - off];
             a8 = s_tot8[tid - off];
+            ab = s_bk[tid - off];
         }
         __syncthreads();
         s_tot[tid] += a;
         s_tot8[tid] += a8;
+        s_bk[tid] += ab;
         __syncthreads();
     }
     int run = s_tot[tid] - sum, run8 = s_tot8[tid] - sum8;
+    unsigned long long rbk = s_bk[tid] - bk;  // sequences of each bucket before this thread's
     for (int j = 0; j < per; ++j) {
         const int s = b0 + j;
         if (s < P.S) {
@@ -129,6 +144,9 @@ __global__ void __launch_bounds__(1024) plan_kernel(const PlanArgs P) {
             const int eff = lc > 0 ? lc : 1;
             P.seq_off[s] = run;
             P.seq_vtcol[s] = run8;
+            const int b = len_bucket(eff);
+            P.desc[P.bstart[b] + (int)((rbk >> (16 * b)) & 0xFFFF)] = make_int4(run, eff, run8, s);
+            rbk += 1ull << (16 * b);
             run += eff;
             run8 += (eff + 7) & ~7;
         }
@@ -588,6 +606,7 @@ struct AnceEncoder {
         float *preA, *preB;      // pre-LayerNorm rows: attention block output / FFN block output (or embeddings)
         float *statsA, *statsB;  // (mean, rstd) per row of preA / preB
         _Float16 *h16, *qk16, *vt16, *ctx16, *ffn16;
+        int4 *desc;              // attention descriptors in length-bucket order
         float *part;             // folded LayerNorm: (mean, M2) of the 64-column slices of the last RES output
         // folded LayerNorm: preA / preB hold the (hi, lo) fp16 pairs of the stream instead of fp32 rows
         _Float16 *xa_hi() const { return reinterpret_cast<_Float16 *>(preA); }
@@ -661,6 +680,7 @@ void layout_workspace(const AnceEncoderDesc *d, Arena &a, AnceEncoder *e) {
         AnceEncoder::Lane L;
         L.seq_off = a.take<int>(scap + 1); L.seq_vtcol = a.take<int>(scap); L.seq_len = a.take<int>(scap);
         L.tok_id = a.take<int>(tcap); L.tok_pos = a.take<int>(tcap); L.tok_vtcol = a.take<int>(tcap);
+        L.desc = a.take<int4>(scap);
         L.preB = a.take<float>((size_t)tcap * H); L.preA = a.take<float>((size_t)tcap * H);
         L.statsA = a.take<float>((size_t)tcap * 2); L.statsB = a.take<float>((size_t)tcap * 2);
         L.h16 = a.take<_Float16>((size_t)tcap * H);
@@ -727,6 +747,7 @@ int encode_impl(AnceEncoder *e, const int32_t *base, int64_t ld, const int32_t *
             hipStream_t st = e->n_lanes > 1 ? e->side[mb_index % e->n_lanes] : caller_st;
             ++mb_index;
             int S = 0, T = 0, V = 0, maxlen = 1;
+            int n_bucket[4] = {0, 0, 0, 0};
             int64_t g = gs;
             while (g < gs_end && S < e->scap) {
                 const int64_t rec = g / n_chunks;
@@ -740,6 +761,8 @@ int encode_impl(AnceEncoder *e, const int32_t *base, int64_t ld, const int32_t *
                 if (T + eff > e->tcap || V + v8 > e->vcap - 256) break;
                 T += eff; V += v8; ++S; ++g;
                 if (eff > maxlen) maxlen = eff;
+                const int nb = (eff + 31) >> 5;
+                ++n_bucket[nb > 4 ? 3 : nb - 1];  // = len_bucket(eff) of plan_kernel
             }
             if (S == 0) {
                 set_last_error("ance_encode: max_tokens too small for one sequence");
@@ -754,6 +777,9 @@ int encode_impl(AnceEncoder *e, const int32_t *base, int64_t ld, const int32_t *
             P.pad_id = D.pad_token_id; P.arch = D.arch; P.T = T; P.Tpad = Tpad;
             P.seq_off = LN.seq_off; P.seq_vtcol = LN.seq_vtcol; P.seq_len = LN.seq_len;
             P.tok_id = LN.tok_id; P.tok_pos = LN.tok_pos; P.tok_vtcol = LN.tok_vtcol;
+            P.desc = LN.desc;
+            P.bstart[3] = 0;  // longest sequences first
+            for (int b = 2; b >= 0; --b) P.bstart[b] = P.bstart[b + 1] + n_bucket[b + 1];
             {
                 ProfScope ps(PC_PLAN, st);
                 hipLaunchKernelGGL(plan_kernel, dim3(1), dim3(1024), 0, st, P);
@@ -806,7 +832,7 @@ int encode_impl(AnceEncoder *e, const int32_t *base, int64_t ld, const int32_t *
                 }
                 if (rc) return rc;
                 AttnArgs A;
-                A.qk = LN.qk16; A.vt = LN.vt16; A.ctx = LN.ctx16; A.seq_off = LN.seq_off; A.seq_vtcol = LN.seq_vtcol;
+                A.qk = LN.qk16; A.vt = LN.vt16; A.ctx = LN.ctx16; A.desc = LN.desc;
                 A.ld_qk = 2 * H; A.ld_vt = ldvt; A.ld_ctx = H; A.n_heads = D.n_heads; A.cls_only = tail ? 1 : 0;
                 {
                     ProfScope ps(PC_ATTN, st, 0.0);
@@ -979,9 +1005,24 @@ extern "C" int ance_encoder_create(const AnceEncoderDesc *desc, const void *cons
     e->ev_fork = nullptr;
     if (e->n_lanes > 1) {
         bool ok = hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) == hipSuccess;
-        for (int ln = 0; ln < e->n_lanes && ok; ++ln)
-            ok = hipStreamCreateWithFlags(&e->side[ln], hipStreamNonBlocking) == hipSuccess &&
-                 hipEventCreateWithFlags(&e->ev_join[ln], hipEventDisableTiming) == hipSuccess;
+        // ANCE_CU_SPLIT (experiment): every lane's stream owns a disjoint share of the CUs, so that the lanes never wait for
+        // each other's workgroups and the epilogue bursts of one lane's GEMM fall into the main loops of the others.
+        // 1: contiguous bit ranges of the 256-bit CU mask, 2: bit % lanes, 3: 32-bit word % lanes
+        const char *cs = getenv("ANCE_CU_SPLIT");
+        const int split = cs ? atoi(cs) : 0;
+        for (int ln = 0; ln < e->n_lanes && ok; ++ln) {
+            if (split >= 1 && split <= 3) {
+                uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                for (int b = 0; b < 256; ++b) {
+                    const int owner = split == 1 ? b / (256 / e->n_lanes) : (split == 2 ? b % e->n_lanes : (b / 32) % e->n_lanes);
+                    if (owner == ln) mask[b >> 5] |= 1u << (b & 31);
+                }
+                ok = hipExtStreamCreateWithCUMask(&e->side[ln], 8, mask) == hipSuccess;
+            } else {
+                ok = hipStreamCreateWithFlags(&e->side[ln], hipStreamNonBlocking) == hipSuccess;
+            }
+            ok = ok && hipEventCreateWithFlags(&e->ev_join[ln], hipEventDisableTiming) == hipSuccess;
+        }
         if (!ok) {
             delete e;
             return check_launch("ance_encoder_create: streams");

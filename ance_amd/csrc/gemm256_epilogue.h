@@ -183,7 +183,7 @@ __device__ __forceinline__ void gemm256_epilogue(const GemmArgs &G, f32x16 (&acc
         const int c4 = l & 15;
         const f32x4 bias = *reinterpret_cast<const f32x4 *>(G.bias + nw0 + c4 * 4);
         const f32x4 lng = *reinterpret_cast<const f32x4 *>(G.res_gamma + nw0 + c4 * 4);
-        const f32x4 lnb = *reinterpret_cast<const f32x4 *>(G.res_beta + nw0 + c4 * 4);
+        const f32x4 bias_beta = bias + *reinterpret_cast<const f32x4 *>(G.res_beta + nw0 + c4 * 4);
         const int n_parts = G.N >> 6, slice = nw0 >> 6;
 #pragma unroll
         for (int y = 0; y < 4; ++y) {
@@ -212,11 +212,15 @@ __device__ __forceinline__ void gemm256_epilogue(const GemmArgs &G, f32x16 (&acc
             for (int it = 0; it < 8; ++it) {
                 const int rr = it * 4 + (l >> 4);
                 const size_t row = (size_t)(mw0 + y * 32 + rr);
-                f32x4 x32;
+                // acc + bias + LayerNorm(hi + lo) = acc + hi a + (lo a + (bias + beta - mean a)),  a = rstd gamma: two
+                // mixed-precision FMAs per element (v_fma_mix_f32 takes the fp16 halves as they are)
+                f32x4 v = *reinterpret_cast<const f32x4 *>(slab + rr * LS + c4 * 4);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) x32[e] = (float)rh[it][e] + (float)rl[it][e];
-                const f32x4 v = *reinterpret_cast<const f32x4 *>(slab + rr * LS + c4 * 4) + bias +
-                                ln_apply4(x32, mean[it], rstd[it], lng, lnb);
+                for (int e = 0; e < 4; ++e) {
+                    const float a = rstd[it] * lng[e];
+                    const float b0 = __builtin_fmaf(-mean[it], a, bias_beta[e]);
+                    v[e] += __builtin_fmaf((float)rh[it][e], a, __builtin_fmaf((float)rl[it][e], a, b0));
+                }
                 const f16x4 hi = f16x4{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
                 const f16x4 lo = f16x4{(_Float16)(v[0] - (float)hi[0]), (_Float16)(v[1] - (float)hi[1]),
                                        (_Float16)(v[2] - (float)hi[2]), (_Float16)(v[3] - (float)hi[3])};
@@ -236,6 +240,9 @@ __device__ __forceinline__ void gemm256_epilogue(const GemmArgs &G, f32x16 (&acc
         // fp16 outputs: slab [64 m][64 n] halves, row stride 72 halves (144 B); 2 passes
         _Float16 *slab = smem + w * 8192;  // 16 KiB per wave
         constexpr int LS = 72;
+        // EPI_QK: the scale (1/8 and log2 e on Q) applies to columns < scale_cols -- a multiple of 64, so a wave's 64 columns
+        // are all in or all out (per element this was a compare, a select and a multiply on every output)
+        const float qscale = (EPI == EPI_QK && nw0 < G.scale_cols) ? G.scale : 1.0f;
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
             epi_sync<WAVE_SYNC>();
@@ -263,8 +270,7 @@ __device__ __forceinline__ void gemm256_epilogue(const GemmArgs &G, f32x16 (&acc
                         if constexpr (EPI == EPI_GELU) {
                             t = gelu_erf256(t);
                         } else {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) t[e] = (nw0 + nl + e) < G.scale_cols ? t[e] * G.scale : t[e];
+                            t = t * qscale;
                         }
                         const f16x4 v = f16x4{(_Float16)t[0], (_Float16)t[1], (_Float16)t[2], (_Float16)t[3]};
                         *reinterpret_cast<f16x4 *>(slab + (yy * 32 + i) * LS + nl) = v;
