@@ -148,6 +148,40 @@ def golden_end_to_end():
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+def golden_end_to_end_maxp():
+    """Config 4: the reference's own generate_new_ann with RobertaDot_CLF_ANN_NLL_MultiChunk (MaxP, 2048 = 4 x 512
+    tokens, drivers/run_ann_data_gen.py:183-189 one slab of vectors per chunk; :383-384,419-423 duplicate pids skipped)
+    on a toy document set whose lengths straddle the 512 / 1024 / 1536 chunk boundaries, so that all-pad chunks -- one
+    identical vector per such chunk -- enter the top-k lists.  CPU, 1-layer model."""
+    import shutil
+    import tempfile
+    tmp = tempfile.mkdtemp(prefix="ance_golden_maxp_")
+    try:
+        data = os.path.join(tmp, "data")
+        dargs = dict(n_passages=56, n_train=24, n_dev=8, L=2048, Lq=32, seed=79, len_median=600, len_sigma=0.9, dup_frac=0.0)
+        synth.make_msmarco_like(data, **dargs)
+        wargs = dict(seed=23, n_layers=1, ln_jitter=0.1)
+        sd = encoder_ref.random_state_dict(**wargs)
+        m = ref_harness.build_reference_model("rdot_nll_multi_chunk", n_layers=1, seed=0)
+        load_into(m, sd)
+        outd = os.path.join(tmp, "out")
+        jargs = dict(max_seq_length=2048, max_query_length=32, topk_training=40, negative_sample=6, ann_chunk_factor=1,
+                     ann_measure_topk_mrr=True, model_type="rdot_nll_multi_chunk")
+        res = ref_harness.run_generate_new_ann(data, outd, m, output_num=0, checkpoint_path="/x/checkpoint-100/", step=100,
+                                               seed=5, **jargs)
+        with open(os.path.join(outd, "ann_training_data_0")) as f:
+            lines = f.read()
+        with open(os.path.join(outd, "ann_ndcg_0")) as f:
+            nd = json.load(f)
+        with open(os.path.join(OUT, "e2e_maxp.json"), "w") as f:
+            json.dump(dict(weights=dict(checksum=sd_checksum(sd), **wargs), data=dargs,
+                           args=dict(seed=5, output_num=0, checkpoint_path="/x/checkpoint-100/", per_gpu_eval_batch_size=16, **jargs),
+                           ann_training_data_0=lines, ann_ndcg_0=nd, result=[res[0], res[1]]), f)
+        return dict(ndcg=nd["ndcg"], lines=lines.count("\n"))
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def golden_dpr():
     """validate / GenerateNegativePassaageID / has_answer of the reference's DPR driver on synthetic
     passages and answers (unicode, punctuation, multi-token and empty-token answers)."""
@@ -271,9 +305,18 @@ def golden_metrics():
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    info = dict(encoder=golden_encoder(), postsearch=golden_postsearch(), e2e=golden_end_to_end(), dpr=golden_dpr(),
-                preprocess=golden_preprocess(), metrics=golden_metrics(), dpr_preprocess=golden_dpr_preprocess(),
-                torch=torch.__version__, numpy=np.__version__)
-    with open(os.path.join(OUT, "manifest.json"), "w") as f:
+    makers = dict(encoder=golden_encoder, postsearch=golden_postsearch, e2e=golden_end_to_end, e2e_maxp=golden_end_to_end_maxp,
+                  dpr=golden_dpr, preprocess=golden_preprocess, metrics=golden_metrics, dpr_preprocess=golden_dpr_preprocess)
+    which = sys.argv[1:] or list(makers)  # `make_golden.py e2e_maxp` regenerates one piece and its manifest entry
+    mpath = os.path.join(OUT, "manifest.json")
+    info = {}
+    if sys.argv[1:] and os.path.exists(mpath):
+        with open(mpath) as f:
+            info = json.load(f)
+        assert info.get("torch") == torch.__version__, "partial regeneration needs the torch build of the manifest"
+    for name in which:
+        info[name] = makers[name]()
+    info["torch"], info["numpy"] = torch.__version__, np.__version__
+    with open(mpath, "w") as f:
         json.dump(info, f, indent=1)
-    print(json.dumps(info, indent=1))
+    print(json.dumps({k: info[k] for k in which}, indent=1))

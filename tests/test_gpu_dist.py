@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _job(rank, world, data, ckpt, out, port):
+def _job(rank, world, data, ckpt, out, port, L=64, max_tokens=16384):
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
     from ance_amd import ann_data_gen as adg
@@ -28,7 +28,7 @@ def _job(rank, world, data, ckpt, out, port):
         dist.init_process_group("gloo", rank=rank, world_size=world)
     args = types.SimpleNamespace(data_dir=data, output_dir=out, cache_dir=out, inference=False, topk_training=100,
                                  negative_sample=8, ann_chunk_factor=1, ann_measure_topk_mrr=False, model_type="rdot_nll",
-                                 max_seq_length=64, max_query_length=32, device=torch.device("cuda", 0), max_tokens=16384)
+                                 max_seq_length=L, max_query_length=32, device=torch.device("cuda", 0), max_tokens=max_tokens)
     train_pos, dev_pos = negatives.load_positive_ids(data)
     random.seed(4321)
     d = adg.Dist()
@@ -60,3 +60,28 @@ def test_multi_rank_refresh_on_one_gpu(tmp_path):
         assert outs[world]["ann_training_data_0"].count("\n") == 1500
     assert outs[2] == outs[1], "2 ranks"
     assert outs[3] == outs[1], "3 ranks"
+
+
+def test_two_rank_refresh_at_512_tokens(tmp_path):
+    """BASELINE configs[2] in miniature: FirstP at seq_len 512 (the long-sequence attention path: 128 queries per round,
+    K / V^T of up to 512 keys in LDS), the corpus sharded over two ranks that share cuda:0, per-shard lists exchanged by
+    query owner and merged -- files byte-identical to the single-rank run."""
+    from safetensors.torch import save_file
+    from oracle import encoder_ref, synth
+    data = str(tmp_path / "data")
+    synth.make_msmarco_like(data, n_passages=3000, n_train=400, n_dev=101, L=512, Lq=32, seed=12, len_median=260, len_sigma=0.6)
+    sd = encoder_ref.random_state_dict(seed=6, n_layers=2, ln_jitter=0.1)
+    ckpt = tmp_path / "checkpoint-100"
+    ckpt.mkdir()
+    save_file({k: v.contiguous() for k, v in sd.items()}, str(ckpt / "model.safetensors"))
+    outs = {}
+    for world in (1, 2):
+        out = str(tmp_path / ("w%d" % world))
+        port = 29650 + (os.getpid() + world) % 2000
+        if world == 1:
+            _job(0, 1, data, str(ckpt) + "/", out, port, 512, 32768)
+        else:
+            torch.multiprocessing.spawn(_job, args=(world, data, str(ckpt) + "/", out, port, 512, 32768), nprocs=world, join=True)
+        outs[world] = {n: open(os.path.join(out, n)).read() for n in ("ann_training_data_0", "ann_ndcg_0")}
+        assert outs[world]["ann_training_data_0"].count("\n") == 400
+    assert outs[2] == outs[1]

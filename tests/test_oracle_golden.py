@@ -123,3 +123,50 @@ def test_end_to_end_refresh_matches_reference(golden_dir, tmp_path):
         assert f.read() == e["ann_training_data_0"]
     with open(os.path.join(out, "ann_ndcg_0")) as f:
         assert json.load(f) == e["ann_ndcg_0"]
+
+
+def test_end_to_end_maxp_refresh_matches_reference(golden_dir, tmp_path):
+    """Config 4 (MaxP, 2048 = 4 x 512 tokens): oracle MaxP encoder + flat IP + restated post-search in the REFERENCE's row
+    order -- per batch of 16 records one slab of vectors per chunk (drivers/run_ann_data_gen.py:183-186,
+    oracle.ann_ref.maxp_row_order) -- reproduce the files the reference's own generate_new_ann wrote with
+    RobertaDot_CLF_ANN_NLL_MultiChunk: all-pad chunks (one identical vector each) compete in the top-k lists and the
+    duplicate-pid skip of GenerateNegativePassaageID (:383-384, 419-423) is what keeps the negatives distinct."""
+    with open(os.path.join(golden_dir, "e2e_maxp.json")) as f:
+        e = json.load(f)
+    sd = _weights(e["weights"])
+    data = str(tmp_path / "data")
+    synth.make_msmarco_like(data, **e["data"])
+    a = e["args"]
+    train_pos, dev_pos = ann_ref.load_positive_ids(data)
+    nl = e["weights"]["n_layers"]
+    bs, chunks = a["per_gpu_eval_batch_size"], a["max_seq_length"] // 512
+
+    def enc_q(name):
+        lens, ids = ann_ref.read_cache(os.path.join(data, name))
+        with torch.no_grad():
+            return encoder_ref.rdot_nll_ln_emb(sd, torch.from_numpy(ids), encoder_ref.mask_from_lengths(lens, a["max_query_length"]),
+                                               n_layers=nl).numpy()
+
+    lens, ids = ann_ref.read_cache(os.path.join(data, "passages"))
+    assert (lens <= 512).any() and (lens > 1536).any()  # the set exercises all-pad chunks and full documents
+    slabs = []
+    with torch.no_grad():
+        for b0 in range(0, len(lens), bs):
+            emb = encoder_ref.rdot_nll_multi_chunk_body_emb(sd, torch.from_numpy(ids[b0:b0 + bs]),
+                                                            encoder_ref.mask_from_lengths(lens[b0:b0 + bs], a["max_seq_length"]),
+                                                            n_layers=nl).numpy()
+            slabs.extend(emb[:, c, :] for c in range(chunks))
+    p_emb = np.concatenate(slabs)
+    p2id = ann_ref.maxp_row_order(len(lens), 1, bs, chunks)
+    assert p_emb.shape[0] == len(lens) * chunks == len(p2id)
+    dev_q, train_q = enc_q("dev-query"), enc_q("train-query")
+    out = str(tmp_path / "out")
+    os.makedirs(out)
+    random.seed(a["seed"])
+    ndcg, _, _, _ = ann_ref.refresh_from_embeddings(
+        out, a["output_num"], a["checkpoint_path"], dev_q, np.arange(len(dev_q)), p_emb, p2id, train_q, np.arange(len(train_q)),
+        train_pos, dev_pos, a["topk_training"], a["negative_sample"], a["ann_chunk_factor"], a["ann_measure_topk_mrr"],
+        search_ref.flat_ip_topk_blas)
+    assert abs(ndcg - e["ann_ndcg_0"]["ndcg"]) < 1e-9
+    with open(os.path.join(out, "ann_training_data_0")) as f:
+        assert f.read() == e["ann_training_data_0"]
