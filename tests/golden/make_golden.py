@@ -158,7 +158,7 @@ def golden_end_to_end_maxp():
     tmp = tempfile.mkdtemp(prefix="ance_golden_maxp_")
     try:
         data = os.path.join(tmp, "data")
-        dargs = dict(n_passages=56, n_train=24, n_dev=8, L=2048, Lq=32, seed=79, len_median=600, len_sigma=0.9, dup_frac=0.0)
+        dargs = dict(n_passages=56, n_train=24, n_dev=8, L=2048, Lq=32, seed=79, len_median=250, len_sigma=1.1, dup_frac=0.0)
         synth.make_msmarco_like(data, **dargs)
         wargs = dict(seed=23, n_layers=1, ln_jitter=0.1)
         sd = encoder_ref.random_state_dict(**wargs)

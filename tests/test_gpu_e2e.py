@@ -14,8 +14,8 @@ import torch
 pytestmark = pytest.mark.gpu
 
 # what the default (fp16-operand) encoder measures on the toy job, with a small margin -- not a loose bound
-E2E_MAX_DELTA_NDCG = 0.05
-E2E_MIN_IDENTICAL_LINES = 0.8
+E2E_MAX_DELTA_NDCG = 0.02      # measured 0.0 (profiles/r03_e2e_agreement.json)
+E2E_MIN_IDENTICAL_LINES = 0.8   # measured 26 of 30
 MAXP_MAX_DELTA_NDCG = 0.05
 MAXP_MIN_IDENTICAL_SETS = 0.7
 
@@ -173,13 +173,14 @@ def test_maxp_refresh_job_end_to_end(golden_dir, tmp_path):
     os.makedirs(out2)
     random.seed(a["seed"])
     p2id = np.arange(n_docs * chunks, dtype=np.int64) // chunks
-    ndcg_o, _, _, I = ann_ref.refresh_from_embeddings(
+    ndcg_o, _, dev_I, I = ann_ref.refresh_from_embeddings(
         out2, 0, nd["checkpoint"], dev_q, np.arange(len(dev_q)), p_emb, p2id, train_q, np.arange(len(train_q)), train_pos,
         dev_pos, a["topk_training"], a["negative_sample"], a["ann_chunk_factor"], a["ann_measure_topk_mrr"],
         search_ref.flat_ip_topk_chain)
     assert open(train_path).read() == open(os.path.join(out2, "ann_training_data_0")).read()
     assert abs(nd["ndcg"] - ndcg_o) < 1e-12
-    assert np.isin(np.asarray(pad_rows), I).any(), "the toy set is meant to put all-pad chunk rows into the top-k lists"
+    # 224 rows, a third of them the all-pad vector: the dev lists (top-100) cannot avoid the class of identical rows
+    assert np.isin(np.asarray(pad_rows), dev_I).any()
     for line in open(train_path):  # no pid twice in a negative list, none equal to the positive
         qid, pos, negs = line.rstrip("\n").split("\t")
         ng = [int(x) for x in negs.split(",")] if negs else []
