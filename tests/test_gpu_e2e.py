@@ -16,8 +16,8 @@ pytestmark = pytest.mark.gpu
 # what the default (fp16-operand) encoder measures on the toy job, with a small margin -- not a loose bound
 E2E_MAX_DELTA_NDCG = 0.02      # measured 0.0 (profiles/r03_e2e_agreement.json)
 E2E_MIN_IDENTICAL_LINES = 0.8   # measured 26 of 30
-MAXP_MAX_DELTA_NDCG = 0.05
-MAXP_MIN_IDENTICAL_SETS = 0.7
+MAXP_MAX_DELTA_NDCG = 0.02      # measured 0.0
+MAXP_MIN_IDENTICAL_SETS = 0.85  # measured 23 of 24 negative sets (22 of 24 lines) identical to the reference's run
 
 
 def _checksum(sd):
