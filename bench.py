@@ -55,6 +55,7 @@ def parse():
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="time budget per CPU-baseline leg")
     p.add_argument("--skip-search", action="store_true")
     p.add_argument("--skip-encode", action="store_true")
+    p.add_argument("--skip-encoder-like", action="store_true", help="skip the second search leg (encoder-like rows)")
     p.add_argument("--full", action="store_true",
                    help="measure ONE real refresh instead of the step benchmark: write the tokenised caches of "
                         "--n-passages passages / --full-queries train queries to --full-dir, then run "
@@ -514,6 +515,36 @@ def main():
                                           "whole_step_tflops": 2.0 * a.query_block * a.n_passages * 768 * a.steps / dt / 1e12,
                                           "hbm_read_gbs_min": ((n_loc * 768 * 2.0) / (scan["ms"] / n_scan * 1e-3) / 1e9)
                                           if scan["ms"] > 0 else None}}
+            # ---- the same leg on ENCODER-LIKE rows: one large common component + small deviations (what a dual encoder
+            # really emits: random-init roberta-base gives cosine 0.99 between any two passages) -- the filter's hard case:
+            # the error slack is a larger share of the score spread, and the query-mean bias build of the kernel runs
+            if not a.skip_encoder_like:
+                del res["DI"], D, I
+                gc_ = torch.Generator(device=dev).manual_seed(777)
+                c = torch.randn((768,), generator=gc_, device=dev)
+                c = c / c.norm() * (768.0 ** 0.5)
+                for b0 in range(0, n_loc, 1 << 20):
+                    b1 = min(b0 + (1 << 20), n_loc)
+                    x[b0:b1] = c[None, :] + 0.12 * torch.randn((b1 - b0, 768), generator=g, device=dev)
+                q.copy_(c[None, :] + 0.12 * torch.randn((a.query_block, 768), generator=gq, device=dev))
+                x.add_(0.0)  # bumps the tensor's version counter: the engine rebuilds its search image
+                for _ in range(max(a.warmup, 1)):
+                    step_search()
+                torch.cuda.synchronize()
+                _lib.profile_enable(True)
+                dt2 = timed_steps(step_search, a.steps, 0, dist_on, torch)
+                prof2 = _lib.profile_read()
+                _lib.profile_enable(False)
+                scan2 = prof2["ip_topk_scan"]
+                D2, _ = res["DI"]
+                out["search"]["encoder_like"] = {
+                    "rows": "common component (norm sqrt 768) + 0.12 N(0,1) per row and per query (tests/test_gpu_search.py:_encoder_like)",
+                    "value": a.query_block * a.steps / dt2, "unit": "queries/s", "ms_per_step": 1e3 * dt2 / a.steps,
+                    "filter_ms_per_launch": scan2["ms"] / max(scan2["count"], 1),
+                    "filter_frac_of_peak": (scan2["work"] / (scan2["ms"] * 1e-3) / 1e12 / PEAK_F16_TF) if scan2["ms"] > 0 else None,
+                    "rescore_ms_per_launch": prof2["ip_topk_rescore"]["ms"] / max(prof2["ip_topk_rescore"]["count"], 1),
+                    "sorted": bool((D2[:, 1:] <= D2[:, :-1]).all().item()) if rank == 0 else None,
+                    "relative_to_layernorm_rows": (a.query_block * a.steps / dt2) / qps}
             del x, q
         except Exception as e:
             import traceback
