@@ -3,8 +3,15 @@ matching, top-k hit accuracy and answer-filtered negatives.
 
 ``has_answer`` follows utils/dpr_utils.py:241-306: NFD-normalise, tokenise with the regex
 ``[\\p{L}\\p{N}\\p{M}]+|[^\\p{Z}\\p{C}]`` (case-insensitive, unicode), lower-case, and look for any
-answer as a contiguous token sub-sequence of the passage.  Passages are tokenised once and cached
-(the reference re-tokenises the same passage for every query that retrieves it).
+answer as a contiguous token sub-sequence of the passage.
+
+How it is computed here (same answers, measured 10 x faster than the token-list walk at 1 M passages x 58,812
+questions x 100 candidates, scripts/bench_dpr_host.py): no token contains a space (\\p{Z} is a separator class), so
+"the answer's tokens are a contiguous run of the passage's tokens" is exactly "' ' + ' '.join(answer tokens) + ' '
+is a substring of ' ' + ' '.join(passage tokens) + ' '" -- one C-speed substring search.  And for an all-ASCII passage
+(most of Wikipedia) the tokenisation itself needs no regex: NFD is the identity, \\p{L}\\p{N}\\p{M} are [A-Za-z0-9],
+\\p{Z} is the space, \\p{C} the control characters, so `translate` (pad every punctuation character with spaces,
+controls -> space), `lower`, `split`, `join` give the same token string.  Anything non-ASCII takes the regex.
 """
 import os
 import unicodedata
@@ -21,44 +28,51 @@ def tokenize_uncased(text):
     return [m.group().lower() for m in _TOKEN_RE.finditer(unicodedata.normalize("NFD", text))]
 
 
+# ASCII fast path: every printable non-alphanumeric character is a token of its own, space and the control characters
+# separate tokens (in ASCII \p{Z} = {0x20}, \p{C} = 0x00-0x1F and 0x7F)
+_ASCII_TABLE = {}
+for _c in range(128):
+    _ch = chr(_c)
+    if _ch.isalnum():
+        continue
+    _ASCII_TABLE[_c] = " " if (_c <= 0x20 or _c == 0x7F) else " " + _ch + " "
+
+
+def token_string(text):
+    """' ' + ' '.join(tokenize_uncased(text)) + ' '  (a single space for a text without tokens)."""
+    toks = text.translate(_ASCII_TABLE).lower().split() if text.isascii() else tokenize_uncased(text)
+    return " " + " ".join(toks) + " " if toks else " "
+
+
 class AnswerMatcher:
     def __init__(self, passages):
         """``passages``: {pid_offset: (text, title)} as built by load_data (run_ann_data_gen_dpr.py:63-109)."""
         self.passages = passages
-        self._tok = {}
         self._ans = {}
 
-    def passage_tokens(self, doc_id):
-        t = self._tok.get(doc_id)
-        if t is None:
-            text = self.passages[doc_id][0]
-            t = tokenize_uncased(text) if text is not None else None
-            self._tok[doc_id] = t
-        return t
-
-    def answer_tokens(self, answer):
-        t = self._ans.get(answer)
-        if t is None:
-            t = tokenize_uncased(answer)
+    def answer_needle(self, answer):
+        """' tok tok ' of an answer string, or None for an answer without tokens (which matches every passage: the
+        reference's range(0, len(text) - 0 + 1) is never empty and [] == text[i:i])."""
+        t = self._ans.get(answer, 0)
+        if t == 0:
+            t = token_string(answer)
+            t = None if t == " " else t
             self._ans[answer] = t
         return t
 
     def has_answer(self, answers, doc_id):
-        text = self.passage_tokens(doc_id)
+        text = self.passages[doc_id][0]
         if text is None:
             return False
-        n = len(text)
+        hay = None
         for a in answers:
-            at = self.answer_tokens(a)
-            m = len(at)
-            if m == 0:
-                if n + 1 > 0:  # the reference's range(0, len(text) - 0 + 1) is non-empty: [] == text[i:i] matches
-                    return True
-                continue
-            first = at[0]
-            for i in range(0, n - m + 1):
-                if text[i] == first and text[i:i + m] == at:
-                    return True
+            needle = self.answer_needle(a)
+            if needle is None:
+                return True
+            if hay is None:
+                hay = token_string(text)
+            if needle in hay:
+                return True
         return False
 
 

@@ -105,3 +105,33 @@ def test_worker_pool_equals_serial(g):
         assert pool.map_rows("hits", [(answers[0], p2id[I[0]].tolist())]) == [dpr._hits_row(m, answers[0], p2id[I[0]].tolist())]
     finally:
         pool.close()
+
+
+def test_token_string_search_is_the_token_list_walk():
+    """has_answer is computed as a substring search over space-joined token strings, with a regex-free tokenisation of
+    ASCII text (ance_amd/dpr.py).  Against the definition -- the reference's token-list walk of utils/dpr_utils.py:241-262
+    on the regex tokens -- for random texts over ASCII letters, digits, every ASCII punctuation and control character,
+    and non-ASCII letters / marks / separators (which take the regex path)."""
+    import random
+    from ance_amd import dpr
+
+    def walk(answers, text):
+        t = dpr.tokenize_uncased(text)
+        for a in answers:
+            at = dpr.tokenize_uncased(a)
+            for i in range(0, len(t) - len(at) + 1):
+                if at == t[i:i + len(at)]:
+                    return True
+        return False
+
+    rnd = random.Random(7)
+    ascii_pool = ["a", "B", "c9", "Zq", "7", "x_y", "don't", "U.S.", "3.14", "a-b", "(", ")", ",", "&", "_", "~", "\t", "\n", "\x0b", "\x1c",
+                  "\x7f", " ", "  ", "\x00", "@", "[", "`", "{", "/"]
+    uni_pool = ascii_pool + ["café", "CAFÉ", "Zürich", "İstanbul", "ﬁ", " ", " ", "naïve", "Ａ", "élan", "​", "日本", "№5"]
+    for pool in (ascii_pool, uni_pool):
+        for _ in range(1500):
+            text = "".join(rnd.choice(pool) + rnd.choice(["", " ", " "]) for _ in range(rnd.randint(0, 25)))
+            answers = ["".join(rnd.choice(pool) + rnd.choice(["", " "]) for _ in range(rnd.randint(0, 3))) for _ in range(rnd.randint(1, 3))]
+            m = dpr.AnswerMatcher({0: (text, "t")})
+            assert m.has_answer(answers, 0) == walk(answers, text), (text, answers)
+            assert dpr.token_string(text) == (" " + " ".join(dpr.tokenize_uncased(text)) + " " if dpr.tokenize_uncased(text) else " ")
