@@ -37,6 +37,7 @@
 #include "attention.h"
 #include "common.h"
 #include "gemm_f16.h"
+#include "precise32.h"
 
 namespace ance {
 namespace {
@@ -568,10 +569,18 @@ __global__ void __launch_bounds__(256) head_ln_kernel(float *out, int S, const f
 
 // ------------------------------------------------------------------------------- host layout --
 
+// ANCE_ENCODER_PRECISE=1: handles created while it is set run the fp32 path of precise32.h (the arena and workspace sizes
+// grow by the fp32 weights and activations, so the size queries read the same switch)
+bool precise_env() {
+    const char *p = getenv("ANCE_ENCODER_PRECISE");
+    return p && p[0] == '1';
+}
+
 struct LayerW {
     _Float16 *wqk, *wv, *wo, *w1, *w2;
     float *bqk, *bv, *bo, *b1, *b2, *ln1w, *ln1b, *ln2w, *ln2b;
     float *cqk, *cv, *c1;  // folded LayerNorm: per-feature sums of the folded fp16 weight rows
+    float *wqkv32, *bqkv32, *wo32, *w132, *w232;  // fp32 path only
 };
 
 struct Arena {
@@ -607,6 +616,7 @@ struct AnceEncoder {
         float *statsA, *statsB;  // (mean, rstd) per row of preA / preB
         _Float16 *h16, *qk16, *vt16, *ctx16, *ffn16;
         int4 *desc;              // attention descriptors in length-bucket order
+        float *x32, *xa32, *qkv32, *ctx32, *ffn32;  // fp32 path only: hidden states, Q|K|V, attention output, FFN activation
         float *part;             // folded LayerNorm: (mean, M2) of the 64-column slices of the last RES output
         // folded LayerNorm: preA / preB hold the (hi, lo) fp16 pairs of the stream instead of fp32 rows
         _Float16 *xa_hi() const { return reinterpret_cast<_Float16 *>(preA); }
@@ -619,6 +629,7 @@ struct AnceEncoder {
     bool cls_tail;  // run the last layer's post-attention part on the [CLS] rows only (ANCE_CLS_TAIL=0 disables)
     bool ln_fold;   // LayerNorm folded into the GEMMs (file header; ANCE_LN_FOLD=0 disables)
     bool head_mfma; // embeddingHead as one fp32 MFMA GEMM (ANCE_HEAD_MFMA=0: one block per sequence)
+    bool precise;   // fp32 path (precise32.h)
 };
 
 namespace {
@@ -656,6 +667,14 @@ void layout_weights(const AnceEncoderDesc *d, Arena &a, AnceEncoder *e) {
         w.cqk = a.take<float>(2 * H);
         w.cv = a.take<float>(H);
         w.c1 = a.take<float>(I);
+        w.wqkv32 = w.bqkv32 = w.wo32 = w.w132 = w.w232 = nullptr;
+        if (precise_env()) {
+            w.wqkv32 = a.take<float>((size_t)3 * H * H);
+            w.bqkv32 = a.take<float>(3 * H);
+            w.wo32 = a.take<float>((size_t)H * H);
+            w.w132 = a.take<float>(I * H);
+            w.w232 = a.take<float>((size_t)H * I);
+        }
         if (e) e->layers[i] = w;
     }
     float *hw = nullptr, *hb = nullptr, *nw = nullptr, *nb = nullptr;
@@ -689,6 +708,14 @@ void layout_workspace(const AnceEncoderDesc *d, Arena &a, AnceEncoder *e) {
         L.ctx16 = a.take<_Float16>((size_t)tcap * H);
         L.ffn16 = a.take<_Float16>((size_t)tcap * d->intermediate);
         L.part = a.take<float>((size_t)tcap * (H / 64) * 2);
+        L.x32 = L.xa32 = L.qkv32 = L.ctx32 = L.ffn32 = nullptr;
+        if (precise_env()) {
+            L.x32 = a.take<float>((size_t)tcap * H);
+            L.xa32 = a.take<float>((size_t)tcap * H);
+            L.qkv32 = a.take<float>((size_t)tcap * 3 * H);
+            L.ctx32 = a.take<float>((size_t)tcap * H);
+            L.ffn32 = a.take<float>((size_t)tcap * d->intermediate);
+        }
         if (e) e->lane[ln] = L;
     }
 }
@@ -785,6 +812,74 @@ int encode_impl(AnceEncoder *e, const int32_t *base, int64_t ld, const int32_t *
                 hipLaunchKernelGGL(plan_kernel, dim3(1), dim3(1024), 0, st, P);
                 const int nb_seq = (S + 3) / 4, nb_pad = (Tpad - T + 255) / 256;
                 hipLaunchKernelGGL(pack_kernel, dim3(nb_seq > nb_pad ? nb_seq : nb_pad), dim3(256), 0, st, P);
+            }
+            if (e->precise) {
+                // ---- fp32 path (precise32.h): plain sequence of fp32 kernels, every layer on every token ----
+                int rc = ANCE_OK;
+                {
+                    ProfScope pe(PC_EMBED, st);
+                    hipLaunchKernelGGL(embed32_kernel, dim3(Tpad / 4), dim3(256), 0, st, LN.tok_id, LN.tok_pos, Tpad, e->word, e->pos,
+                                       e->type0, D.vocab_size, D.max_position, LN.preB);
+                    hipLaunchKernelGGL(ln32_kernel, dim3(Tpad / 4), dim3(256), 0, st, LN.preB, Tpad, e->eln_w, e->eln_b, D.ln_eps,
+                                       LN.x32, (float *)nullptr);
+                }
+                for (int li = 0; li < D.n_layers && !rc; ++li) {
+                    const LayerW &W = e->layers[li];
+                    const bool last = li == D.n_layers - 1;
+                    {
+                        ProfScope ps(PC_GEMM_QK, st, 2.0 * T * (3.0 * H) * H);
+                        rc = launch_gemm32(P_EPI_BIAS, LN.x32, H, W.wqkv32, H, W.bqkv32, nullptr, 0, LN.qkv32, 3 * H, Tpad, 3 * H, H, st);
+                    }
+                    if (rc) break;
+                    {
+                        ProfScope ps(PC_ATTN, st);
+                        rc = launch_attention32(LN.qkv32, LN.ctx32, LN.seq_off, S, D.n_heads, st);
+                    }
+                    if (rc) break;
+                    {
+                        ProfScope ps(PC_GEMM_OUT, st, 2.0 * T * (double)H * H);
+                        rc = launch_gemm32(P_EPI_RES, LN.ctx32, H, W.wo32, H, W.bo, LN.x32, H, LN.preA, H, Tpad, H, H, st);
+                    }
+                    if (rc) break;
+                    {
+                        ProfScope ps(PC_LN, st);
+                        hipLaunchKernelGGL(ln32_kernel, dim3(Tpad / 4), dim3(256), 0, st, LN.preA, Tpad, W.ln1w, W.ln1b, D.ln_eps, LN.xa32,
+                                           (float *)nullptr);
+                    }
+                    {
+                        ProfScope ps(PC_GEMM_FFN1, st, 2.0 * T * (double)I * H);
+                        rc = launch_gemm32(P_EPI_GELU, LN.xa32, H, W.w132, H, W.b1, nullptr, 0, LN.ffn32, I, Tpad, I, H, st);
+                    }
+                    if (rc) break;
+                    {
+                        ProfScope ps(PC_GEMM_FFN2, st, 2.0 * T * (double)I * H);
+                        rc = launch_gemm32(P_EPI_RES, LN.ffn32, I, W.w232, I, W.b2, LN.xa32, H, LN.preB, H, Tpad, H, I, st);
+                    }
+                    if (rc) break;
+                    {
+                        ProfScope ps(PC_LN, st);
+                        hipLaunchKernelGGL(ln32_kernel, dim3(Tpad / 4), dim3(256), 0, st, LN.preB, Tpad, W.ln2w, W.ln2b, D.ln_eps, LN.x32,
+                                           last ? LN.statsB : (float *)nullptr);
+                    }
+                }
+                if (rc) return rc;
+                {
+                    ProfScope ps(PC_HEAD, st);
+                    const LayerW &WL = e->layers[D.n_layers - 1];
+                    float *dst = d_out + (size_t)(r0 * n_chunks + gs) * HEAD_OUT;
+                    if (D.has_head) {
+                        hipLaunchKernelGGL(head_gemm_kernel, dim3((S + 31) / 32, HEAD_OUT / 128), dim3(256), HEAD_LDS_BYTES, st, LN.preB,
+                                           (const _Float16 *)nullptr, (const _Float16 *)nullptr, LN.statsB, WL.ln2w, WL.ln2b, LN.seq_off, 0,
+                                           S, e->head_w, e->head_b, dst);
+                        hipLaunchKernelGGL(head_ln_kernel, dim3((S + 3) / 4), dim3(256), 0, st, dst, S, e->norm_w, e->norm_b);
+                    } else {
+                        hipLaunchKernelGGL(head_kernel, dim3(S), dim3(256), 0, st, LN.preB, (const _Float16 *)nullptr,
+                                           (const _Float16 *)nullptr, LN.statsB, WL.ln2w, WL.ln2b, LN.seq_off, 0, e->head_w, e->head_b,
+                                           e->norm_w, e->norm_b, 0, dst);
+                    }
+                }
+                gs = g;
+                continue;
             }
             const bool fold = e->ln_fold;
             // folded LayerNorm: the two halves of the fp16 pair of a stream share the fp32 row's 3 KB
@@ -995,6 +1090,8 @@ extern "C" int ance_encoder_create(const AnceEncoderDesc *desc, const void *cons
         e->ln_fold = !(lf && lf[0] == '0');
         const char *hm = getenv("ANCE_HEAD_MFMA");
         e->head_mfma = !(hm && hm[0] == '0');
+        e->precise = precise_env();
+        if (e->precise) e->ln_fold = false;  // the fp32 path takes the plain biases and LayerNorm parameters
         const char *ns = getenv("ANCE_ENCODER_STREAMS");
         e->n_lanes = (ns && ns[0] >= '1' && ns[0] <= '0' + MAX_LANES) ? ns[0] - '0' : 2;
     }
@@ -1077,6 +1174,17 @@ extern "C" int ance_encoder_create(const AnceEncoderDesc *desc, const void *cons
         cpy32(p[7], L.bo, H, st);
         cpy32(p[8], L.ln1w, H, st);
         cpy32(p[9], L.ln1b, H, st);
+        if (e->precise) {
+            cpy32(p[0], L.wqkv32, (size_t)H * H, st);
+            cpy32(p[2], L.wqkv32 + (size_t)H * H, (size_t)H * H, st);
+            cpy32(p[4], L.wqkv32 + (size_t)2 * H * H, (size_t)H * H, st);
+            cpy32(p[1], L.bqkv32, H, st);
+            cpy32(p[3], L.bqkv32 + H, H, st);
+            cpy32(p[5], L.bqkv32 + 2 * H, H, st);
+            cpy32(p[6], L.wo32, (size_t)H * H, st);
+            cpy32(p[10], L.w132, I * H, st);
+            cpy32(p[12], L.w232, (size_t)H * I, st);
+        }
         cvt16(p[12], L.w2, (size_t)H * I, st);
         cpy32(p[13], L.b2, H, st);
         cpy32(p[14], L.ln2w, H, st);

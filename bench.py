@@ -55,6 +55,7 @@ def parse():
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="time budget per CPU-baseline leg")
     p.add_argument("--skip-search", action="store_true")
     p.add_argument("--skip-encode", action="store_true")
+    p.add_argument("--skip-precise", action="store_true", help="skip the fp32-mode encoder sample")
     p.add_argument("--skip-encoder-like", action="store_true", help="skip the second search leg (encoder-like rows)")
     p.add_argument("--full", action="store_true",
                    help="measure ONE real refresh instead of the step benchmark: write the tokenised caches of "
@@ -439,6 +440,34 @@ def main():
                              "end_to_end_mfma_frac": world * flops_alg * a.steps / dt / 1e12 / (PEAK_F16_TF * world),
                              "hbm_min_bytes_per_passage": 4 + 4 * a.seq_len + 3072,
                              "full_corpus_seconds_est": N_PASSAGES / pps}
+            # ---- the fp32 mode (ANCE_ENCODER_PRECISE=1, csrc/precise32.h) beside the default: rate, and how far the default's
+            # fp16-operand embeddings are from it on the same records (the stated tolerance, measured live)
+            if not a.skip_precise:
+                nb = min(a.encode_block, 4096)
+                os.environ["ANCE_ENCODER_PRECISE"] = "1"
+                try:
+                    encp = Encoder(sd_for_probe, ARCH_ROBERTA, "roberta.", True, max_seq_len=min(a.seq_len, 512),
+                                   max_tokens=a.max_tokens, device=dev)
+                finally:
+                    os.environ.pop("ANCE_ENCODER_PRECISE", None)
+                embp = torch.empty((nb, 768), dtype=torch.float32, device=dev)
+                encp.encode_records(rec_d[:nb], h_lens=lens[:nb], out=embp)
+                torch.cuda.synchronize()
+                tp = time.perf_counter()
+                for _ in range(2):
+                    encp.encode_records(rec_d[:nb], h_lens=lens[:nb], out=embp)
+                torch.cuda.synchronize()
+                dtp = (time.perf_counter() - tp) / 2
+                enc.encode_records(rec_d, h_lens=lens, out=emb)
+                torch.cuda.synchronize()
+                diff = (emb[:nb] - embp).abs()
+                out["encoder_modes"] = {
+                    "default": {"operands": "fp16 MFMA operands, fp32 accumulation, LayerNorm folded into the GEMMs, residual stream as fp16 (hi, lo) pairs",
+                                "passages_per_sec": pps},
+                    "fp32 (ANCE_ENCODER_PRECISE=1)": {"operands": "fp32 operands on v_mfma_f32_32x32x2_f32, exact erf GELU, fp32 softmax (the reference's arithmetic)",
+                                                      "passages_per_sec": world * nb / dtp, "sample": "%d passages x 2 passes" % nb},
+                    "max_abs_default_vs_fp32": float(diff.max().item()), "mean_abs_default_vs_fp32": float(diff.mean().item())}
+                del encp, embp
             del enc, rec_d, emb, sd_for_probe
             torch.cuda.empty_cache()
         except Exception as e:  # keep going: a bench line with the other leg is still informative
@@ -561,12 +590,16 @@ def main():
         except Exception as e:
             errors["cpu_baseline"] = repr(e)
     try:  # measured by tests/test_gpu_retrieval.py on an MI355X (fp16-operand encoder vs the fp32 reference arithmetic)
-        with open(os.path.join(ROOT, "profiles", "r02_retrieval_agreement.json")) as f:
+        src = "r03_retrieval_agreement.json" if os.path.exists(os.path.join(ROOT, "profiles", "r03_retrieval_agreement.json")) \
+            else "r02_retrieval_agreement.json"
+        with open(os.path.join(ROOT, "profiles", src)) as f:
             ra = json.load(f)
-        out["retrieval_agreement"] = {k_: ra[k_] for k_ in ("n_passages", "n_queries", "layers", "k", "max_abs_passage",
-                                                             "recall_at_200", "identical_top1", "first_20_negatives_overlap",
-                                                             "identical_first_20_negatives")}
-        out["retrieval_agreement"]["source"] = "profiles/r02_retrieval_agreement.json (tests/test_gpu_retrieval.py)"
+        keys = ("n_passages", "n_queries", "layers", "k", "max_abs_passage", "recall_at_200", "identical_top1",
+                "first_20_negatives_overlap", "identical_first_20_negatives")
+        out["retrieval_agreement"] = {k_: ra[k_] for k_ in keys}
+        if "precise_mode" in ra:
+            out["retrieval_agreement"]["fp32_mode"] = {k_: ra["precise_mode"][k_] for k_ in keys}
+        out["retrieval_agreement"]["source"] = "profiles/%s (tests/test_gpu_retrieval.py: both encoder modes against the fp32 oracle)" % src
     except Exception:
         pass
     if errors:

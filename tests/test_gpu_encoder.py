@@ -178,6 +178,40 @@ def test_many_short_queries_cross_micro_batches():
     _report("short_queries", got[pick], want)
 
 
+def test_fp32_mode_against_oracle(monkeypatch):
+    """ANCE_ENCODER_PRECISE=1 (csrc/precise32.h): fp32 operands on the fp32-input matrix cores, exact erf GELU, fp32
+    softmax -- the reference's arithmetic (model/models.py:149-157).  Against the fp32 oracle only the summation order
+    differs: stated tolerance 2e-5 on unit-variance rows (12 layers, L = 128; 3 layers, L = 512)."""
+    from ance_amd.encoder import ARCH_ROBERTA, Encoder
+    from oracle import encoder_ref, synth
+    monkeypatch.setenv("ANCE_ENCODER_PRECISE", "1")
+    sd = encoder_ref.random_state_dict(seed=5, n_layers=12, ln_jitter=0.1)
+    rng = np.random.default_rng(8)
+    lens = np.array([1, 2, 31, 32, 33, 63, 64, 65, 96, 127, 128, 128, 70, 9, 100, 50, 77, 128, 3, 45], dtype=np.int32)
+    ids = synth.make_records(rng, len(lens), 128, lens.astype(np.int64))
+    with torch.no_grad():
+        want = encoder_ref.rdot_nll_ln_emb(sd, torch.from_numpy(ids), encoder_ref.mask_from_lengths(lens, 128)).numpy()
+    enc = Encoder(sd, ARCH_ROBERTA, "roberta.", True, max_seq_len=128, max_tokens=2048)
+    got = enc.encode_ids(torch.from_numpy(ids).cuda(), torch.from_numpy(lens).cuda(), h_lens=lens).cpu().numpy()
+    assert np.isfinite(got).all()
+    d = float(np.abs(got - want).max())
+    with open(os.path.join(OUT, "encoder_parity.jsonl"), "a") as f:
+        f.write(json.dumps(dict(case="fp32_mode_full_depth_L128", max_abs=d)) + "\n")
+    assert d <= 2e-5, d
+    del enc
+    sd3 = encoder_ref.random_state_dict(seed=6, n_layers=3, ln_jitter=0.1)
+    lens5 = np.array([512, 511, 300, 129, 385, 512, 17, 256], dtype=np.int32)
+    ids5 = synth.make_records(np.random.default_rng(9), len(lens5), 512, lens5.astype(np.int64))
+    with torch.no_grad():
+        want5 = encoder_ref.rdot_nll_ln_emb(sd3, torch.from_numpy(ids5), encoder_ref.mask_from_lengths(lens5, 512), n_layers=3).numpy()
+    enc = Encoder(sd3, ARCH_ROBERTA, "roberta.", True, max_seq_len=512, max_tokens=2048)
+    got5 = enc.encode_ids(torch.from_numpy(ids5).cuda(), torch.from_numpy(lens5).cuda(), h_lens=lens5).cpu().numpy()
+    d5 = float(np.abs(got5 - want5).max())
+    with open(os.path.join(OUT, "encoder_parity.jsonl"), "a") as f:
+        f.write(json.dumps(dict(case="fp32_mode_L512", max_abs=d5)) + "\n")
+    assert d5 <= 2e-5, d5
+
+
 def test_missing_extension_is_loud(monkeypatch, tmp_path):
     from ance_amd import _lib
     monkeypatch.setattr(_lib, "_lib", None)

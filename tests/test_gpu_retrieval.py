@@ -39,7 +39,7 @@ def _fp32_reference(sd_dev, ids, lens, L, batch=512):
     return out
 
 
-def test_retrieval_agreement_fp16_operands_vs_fp32_reference():
+def test_retrieval_agreement_fp16_operands_vs_fp32_reference(monkeypatch):
     from ance_amd.encoder import ARCH_ROBERTA, Encoder
     from ance_amd.index import FlatIPIndex
     from oracle import encoder_ref, synth
@@ -56,19 +56,20 @@ def test_retrieval_agreement_fp16_operands_vs_fp32_reference():
         m = int(min(qlen[q], plen[pos[q]])) - 1
         qids[q, 1:m] = pids[pos[q], 1:m]
 
-    enc = Encoder(sd, ARCH_ROBERTA, "roberta.", True, max_seq_len=L, max_tokens=65536)
-    p16 = torch.empty((n_p, 768), dtype=torch.float32, device="cuda")
-    for b0 in range(0, n_p, 16384):
-        b1 = min(b0 + 16384, n_p)
-        p16[b0:b1] = enc.encode_ids(torch.from_numpy(pids[b0:b1]).cuda(), torch.from_numpy(plen[b0:b1]).cuda(), h_lens=plen[b0:b1])
-    q16 = enc.encode_ids(torch.from_numpy(np.pad(qids, ((0, 0), (0, L - Lq)), constant_values=1)).cuda(),
-                         torch.from_numpy(qlen).cuda(), h_lens=qlen)
-    del enc
+    def encode_all():
+        enc = Encoder(sd, ARCH_ROBERTA, "roberta.", True, max_seq_len=L, max_tokens=65536)
+        p = torch.empty((n_p, 768), dtype=torch.float32, device="cuda")
+        for b0 in range(0, n_p, 16384):
+            b1 = min(b0 + 16384, n_p)
+            p[b0:b1] = enc.encode_ids(torch.from_numpy(pids[b0:b1]).cuda(), torch.from_numpy(plen[b0:b1]).cuda(), h_lens=plen[b0:b1])
+        q = enc.encode_ids(torch.from_numpy(np.pad(qids, ((0, 0), (0, L - Lq)), constant_values=1)).cuda(),
+                           torch.from_numpy(qlen).cuda(), h_lens=qlen)
+        del enc
+        return p, q
+
     sd_dev = {k_: v.cuda() for k_, v in sd.items()}
     p32 = _fp32_reference(sd_dev, pids, plen, L)
     q32 = _fp32_reference(sd_dev, qids, qlen, Lq)
-    d_p = (p16 - p32).abs().max().item()
-    d_q = (q16 - q32).abs().max().item()
 
     def topk(x, q):
         idx = FlatIPIndex(768)
@@ -76,34 +77,43 @@ def test_retrieval_agreement_fp16_operands_vs_fp32_reference():
         D, I = idx.search(q, k)
         return D.cpu().numpy(), I.cpu().numpy()
 
-    D16, I16 = topk(p16, q16)
     D32, I32 = topk(p32, q32)
-    recall = float(np.mean([len(np.intersect1d(I16[r], I32[r])) / k for r in range(n_q)]))
-    same_set = float(np.mean([np.array_equal(np.sort(I16[r]), np.sort(I32[r])) for r in range(n_q)]))
-    same_list = float(np.mean(np.all(I16 == I32, axis=1)))
-    same_top1 = float(np.mean(I16[:, 0] == I32[:, 0]))
 
     def negs(I):
-        out = []
-        for r in range(n_q):
-            row = [int(p) for p in I[r, :neg + 1] if p != pos[r]][:neg]
-            out.append(row)
-        return out
+        return [[int(p) for p in I[r, :neg + 1] if p != pos[r]][:neg] for r in range(n_q)]
 
-    n16, n32 = negs(I16), negs(I32)
-    same_neg = float(np.mean([a == b for a, b in zip(n16, n32)]))
-    neg_overlap = float(np.mean([len(set(a) & set(b)) / neg for a, b in zip(n16, n32)]))
-    # rank displacement of the fp32 lists inside the fp16 lists: how far do swapped neighbours move?
-    gap = float(np.median(D32[:, 0] - D32[:, -1]))
-    res = dict(n_passages=n_p, n_queries=n_q, layers=12, k=k, max_abs_passage=d_p, max_abs_query=d_q, recall_at_200=recall,
-               identical_top200_set=same_set, identical_top200_list=same_list, identical_top1=same_top1,
-               identical_first_20_negatives=same_neg, first_20_negatives_overlap=neg_overlap,
-               median_score_span_top200=gap, planted_found_fp16=float(np.mean(I16[:n_q // 2, 0] == pos[:n_q // 2])),
-               planted_found_fp32=float(np.mean(I32[:n_q // 2, 0] == pos[:n_q // 2])))
+    n32 = negs(I32)
+
+    def agreement(p16, q16):
+        d_p = (p16 - p32).abs().max().item()
+        d_q = (q16 - q32).abs().max().item()
+        _, I16 = topk(p16, q16)
+        n16 = negs(I16)
+        return dict(n_passages=n_p, n_queries=n_q, layers=12, k=k, max_abs_passage=d_p, max_abs_query=d_q,
+                    recall_at_200=float(np.mean([len(np.intersect1d(I16[r], I32[r])) / k for r in range(n_q)])),
+                    identical_top200_set=float(np.mean([np.array_equal(np.sort(I16[r]), np.sort(I32[r])) for r in range(n_q)])),
+                    identical_top200_list=float(np.mean(np.all(I16 == I32, axis=1))),
+                    identical_top1=float(np.mean(I16[:, 0] == I32[:, 0])),
+                    identical_first_20_negatives=float(np.mean([a == b for a, b in zip(n16, n32)])),
+                    first_20_negatives_overlap=float(np.mean([len(set(a) & set(b)) / neg for a, b in zip(n16, n32)])),
+                    median_score_span_top200=float(np.median(D32[:, 0] - D32[:, -1])),
+                    planted_found=float(np.mean(I16[:n_q // 2, 0] == pos[:n_q // 2])),
+                    planted_found_fp32=float(np.mean(I32[:n_q // 2, 0] == pos[:n_q // 2])))
+
+    # default mode: fp16 MFMA operands (folded LayerNorm, fp16 (hi, lo) residual stream)
+    monkeypatch.delenv("ANCE_ENCODER_PRECISE", raising=False)
+    res = agreement(*encode_all())
+    # fp32 mode (csrc/precise32.h): what is left is the summation order of two fp32 implementations
+    monkeypatch.setenv("ANCE_ENCODER_PRECISE", "1")
+    res_p = agreement(*encode_all())
+    monkeypatch.delenv("ANCE_ENCODER_PRECISE", raising=False)
     os.makedirs(OUT, exist_ok=True)
     with open(os.path.join(OUT, "retrieval_agreement.json"), "w") as f:
-        json.dump(res, f, indent=1)
-    assert d_p <= 5e-3 and d_q <= 5e-3, res
-    assert recall >= 0.985, res
-    assert neg_overlap >= 0.97, res
-    assert same_top1 >= 0.99, res
+        json.dump(dict(res, precise_mode=res_p), f, indent=1)
+    assert res["max_abs_passage"] <= 5e-3 and res["max_abs_query"] <= 5e-3, res
+    assert res["recall_at_200"] >= 0.985, res
+    assert res["first_20_negatives_overlap"] >= 0.97, res
+    assert res["identical_top1"] >= 0.99, res
+    assert res_p["max_abs_passage"] <= 5e-5 and res_p["max_abs_query"] <= 5e-5, res_p
+    assert res_p["recall_at_200"] >= 0.9995, res_p
+    assert res_p["identical_first_20_negatives"] >= 0.9, res_p
