@@ -21,13 +21,15 @@
 // "LayerNorm without a kernel" (default; ANCE_LN_FOLD=0 selects the form above): the two LayerNorm passes of a layer
 // read 3 KB and write 1.5 KB per token at the HBM roofline for arithmetic every consumer can do on the fly.  Instead
 //   * the RES GEMM epilogue (EPI_RESLN) writes its output row v as an fp16 pair (hi = fp16(v), lo = fp16(v - hi): the same
-//     3 KB the fp32 row took, 22 mantissa bits) and the (mean, M2) of every 64-column slice; ln_finalize_kernel (T rows x
-//     96 bytes) combines the 12 slices of a row into (mean, rstd);
+//     3 KB the fp32 row took, 22 mantissa bits) and the (mean, M2) of every 64-column slice (96 bytes per row);
 //   * the consumer GEMMs take hi AS IT IS for their token operand and finish the normalisation algebraically:
 //       LN(v) W^T + b = r (v (gamma (.) W)^T - mu c) + (b + W beta),   c[n] = sum_k fp16(gamma_k W[n][k])
 //     with gamma folded into the fp16 weight when it is loaded, c summed over the ROUNDED weights (so that the identity is
 //     exact for the products the MFMA actually forms) and b' in fp32;
-//   * the consumers of the fp32 value (next RES epilogue, [CLS] gather, head) recompute LN(hi + lo) as before.
+//   * every consumer combines the 12 slices of a row into (mean, rstd) itself (Chan): a GEMM tile gets the partials of
+//     its 256 tokens, with its bias / csum / gamma / beta vectors, by LDS-DMA ahead of its main loop and combines them
+//     when its epilogue starts -- there is no LayerNorm kernel and no statistics kernel at all;
+//   * the consumers of the fp32 value (next RES epilogue, [CLS] gather, head) recompute LN(hi + lo) from the pair.
 // Rounding points that move: the token operand is fp16(v) instead of fp16(LN(v)) -- the same relative rounding of every
 // element, taken before the mean is removed -- and gamma (.) W is rounded once instead of W.  Measured parity: DESIGN.md 4.
 #include <stdlib.h>
@@ -293,7 +295,7 @@ __global__ void __launch_bounds__(256) gather_cls_kernel(const float *pre, const
 }
 
 __global__ void __launch_bounds__(256) head_kernel(const float *pre, const _Float16 *hi, const _Float16 *lo, const float *stats,
-                                                   const float *lng, const float *lnb,
+                                                   const float *part, float eps, const float *lng, const float *lnb,
                                                    const int *seq_off, int compact, const float *W, const float *b,
                                                    const float *gamma, const float *beta, int has_head, float *out) {
     __shared__ float cls[H];
@@ -301,7 +303,9 @@ __global__ void __launch_bounds__(256) head_kernel(const float *pre, const _Floa
     __shared__ float red[8];
     const int s = blockIdx.x, tid = threadIdx.x;
     const size_t row = (size_t)(compact ? s : seq_off[s]);  // compact: row s already is the [CLS] row
-    const float mean_h = stats[2 * row], rstd_h = stats[2 * row + 1];  // h = LN(pre), recomputed (file header)
+    float mean_h, rstd_h;  // h = LN(pre), recomputed (file header)
+    if (part) stats_from_parts(part + row * 24, eps, &mean_h, &rstd_h);
+    else { mean_h = stats[2 * row]; rstd_h = stats[2 * row + 1]; }
     float *dst = out + (size_t)s * HEAD_OUT;
     auto src = [&](int j) { return hi ? (float)hi[row * H + j] + (float)lo[row * H + j] : pre[row * H + j]; };
     if (!has_head) {
@@ -356,10 +360,11 @@ __device__ __forceinline__ f32x4 pair_load(const _Float16 *hi, const _Float16 *l
     return f32x4{(float)h[0] + (float)r[0], (float)h[1] + (float)r[1], (float)h[2] + (float)r[2], (float)h[3] + (float)r[3]};
 }
 
-// embeddings -> (hi, lo) pair of the pre-LayerNorm row + its (mean, rstd); one wave per token
+// embeddings -> (hi, lo) pair of the pre-LayerNorm row + the (mean, M2) of its twelve 64-column slices (the format the
+// RES epilogue leaves: gemm_f16.h); one wave per token, 16 lanes per slice
 __global__ void __launch_bounds__(256) embed_fold_kernel(const int *tok_id, const int *tok_pos, int Tpad, const float *word,
-                                                         const float *pos, const float *type0, int vocab, int max_pos, float eps,
-                                                         _Float16 *hi, _Float16 *lo, float *stats) {
+                                                         const float *pos, const float *type0, int vocab, int max_pos,
+                                                         _Float16 *hi, _Float16 *lo, float *part) {
     const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int l = threadIdx.x & 63;
     if (t >= Tpad) return;
@@ -369,54 +374,26 @@ __global__ void __launch_bounds__(256) embed_fold_kernel(const int *tok_id, cons
     const f32x4 *w4 = reinterpret_cast<const f32x4 *>(word + (size_t)id * H);
     const f32x4 *p4 = reinterpret_cast<const f32x4 *>(pos + (size_t)p * H);
     const f32x4 *t4 = reinterpret_cast<const f32x4 *>(type0);
-    f32x4 v[3];
-    float s = 0.f;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        const int c4 = k * 64 + l;
-        v[k] = (w4[c4] + t4[c4]) + p4[c4];  // same association as the reference: (word + type) + pos
-        split_store(v[k], hi + (size_t)t * H, lo + (size_t)t * H, c4);
-        s += (v[k][0] + v[k][1]) + (v[k][2] + v[k][3]);
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
-    const float mean = s * (1.0f / H);
-    float q = 0.f;
-#pragma unroll
-    for (int k = 0; k < 3; ++k)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float a = v[k][j] - mean;
-            q += a * a;
+        const int c4 = k * 64 + l;  // columns 4 c4 .. 4 c4 + 3: slice 4 k + l / 16
+        const f32x4 v = (w4[c4] + t4[c4]) + p4[c4];  // same association as the reference: (word + type) + pos
+        split_store(v, hi + (size_t)t * H, lo + (size_t)t * H, c4);
+        const float m64 = row16_sum((v[0] + v[1]) + (v[2] + v[3])) * (1.0f / 64.0f);
+        const float d0 = v[0] - m64, d1 = v[1] - m64, d2 = v[2] - m64, d3 = v[3] - m64;
+        const float q64 = row16_sum((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3));
+        if ((l & 15) == 0) {
+            float *pp = part + ((size_t)t * 12 + 4 * k + (l >> 4)) * 2;
+            pp[0] = m64;
+            pp[1] = q64;
         }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) q += __shfl_xor(q, off);
-    if (l == 0) {
-        stats[2 * (size_t)t] = mean;
-        stats[2 * (size_t)t + 1] = rsqrtf(q * (1.0f / H) + eps);
     }
 }
 
-// (mean, M2) of the n_parts 64-column slices of a row (EPI_RESLN) -> (mean, rstd) of the row.  Chan's combination
-// with equal counts: mean = avg(mean_i), M2 = sum M2_i + 64 sum (mean_i - mean)^2.  One thread per row.
-__global__ void __launch_bounds__(256) ln_finalize_kernel(const float *part, int n_parts, int rows, float eps, float *stats) {
-    const int r = blockIdx.x * 256 + threadIdx.x;
-    if (r >= rows) return;
-    const float2 *pp = reinterpret_cast<const float2 *>(part) + (size_t)r * n_parts;
-    float m = 0.f, q = 0.f;
-    for (int j = 0; j < n_parts; ++j) m += pp[j].x;
-    m *= 1.0f / (float)n_parts;
-    for (int j = 0; j < n_parts; ++j) {
-        const float d = pp[j].x - m;
-        q += pp[j].y + 64.0f * d * d;
-    }
-    reinterpret_cast<float2 *>(stats)[r] = make_float2(m, rsqrtf(q / (64.0f * (float)n_parts) + eps));
-}
-
-// last layer, CLS-only tail: compact (hi, lo, stats) rows of the [CLS] tokens; rows S..S_pad zeroed
-__global__ void __launch_bounds__(256) gather_cls_fold_kernel(const _Float16 *hi, const _Float16 *lo, const float *stats,
+// last layer, CLS-only tail: compact (hi, lo, slice partials) rows of the [CLS] tokens; rows S..S_pad zeroed
+__global__ void __launch_bounds__(256) gather_cls_fold_kernel(const _Float16 *hi, const _Float16 *lo, const float *part,
                                                               const int *seq_off, int S, int S_pad, _Float16 *chi, _Float16 *clo,
-                                                              float *cstats) {
+                                                              float *cpart) {
     const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int l = threadIdx.x & 63;
     if (s >= S_pad) return;
@@ -429,10 +406,7 @@ __global__ void __launch_bounds__(256) gather_cls_fold_kernel(const _Float16 *hi
             dh[k * 64 + l] = sh[k * 64 + l];
             dl[k * 64 + l] = sl[k * 64 + l];
         }
-        if (l == 0) {
-            cstats[2 * s] = stats[2 * row];
-            cstats[2 * s + 1] = stats[2 * row + 1];
-        }
+        if (l < 24) cpart[(size_t)s * 24 + l] = part[row * 24 + l];
     } else {
         const f16x4 z = {0, 0, 0, 0};
 #pragma unroll
@@ -440,10 +414,7 @@ __global__ void __launch_bounds__(256) gather_cls_fold_kernel(const _Float16 *hi
             dh[k * 64 + l] = z;
             dl[k * 64 + l] = z;
         }
-        if (l == 0) {
-            cstats[2 * s] = 0.f;
-            cstats[2 * s + 1] = 0.f;
-        }
+        if (l < 24) cpart[(size_t)s * 24 + l] = (l & 1) ? 64.0f : 0.f;  // mean 0, variance 1: a finite rstd
     }
 }
 
@@ -485,8 +456,9 @@ constexpr int HEAD_LDA = H + 4;  // floats; 16 lanes x stride 4 banks: conflict-
 constexpr size_t HEAD_LDS_BYTES = (size_t)32 * HEAD_LDA * sizeof(float);
 
 __global__ void __launch_bounds__(256) head_gemm_kernel(const float *pre32, const _Float16 *hi, const _Float16 *lo,
-                                                        const float *stats, const float *lng, const float *lnb, const int *seq_off,
-                                                        int compact, int S, const float *W, const float *b, float *out) {
+                                                        const float *stats, const float *part, float eps, const float *lng,
+                                                        const float *lnb, const int *seq_off, int compact, int S, const float *W,
+                                                        const float *b, float *out) {
     extern __shared__ __attribute__((aligned(16))) float cls[];
     const int s0 = blockIdx.x * 32, n0 = blockIdx.y * 128;
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, g = l >> 5, i = l & 31;
@@ -496,7 +468,9 @@ __global__ void __launch_bounds__(256) head_gemm_kernel(const float *pre32, cons
         f32x4 *dst = reinterpret_cast<f32x4 *>(cls + r * HEAD_LDA);
         if (s < S) {
             const size_t row = (size_t)(compact ? s : seq_off[s]);
-            const float mean = stats[2 * row], rstd = stats[2 * row + 1];
+            float mean, rstd;
+            if (part) stats_from_parts(part + row * 24, eps, &mean, &rstd);  // (every lane: 24 cached floats)
+            else { mean = stats[2 * row]; rstd = stats[2 * row + 1]; }
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
                 const int c4 = k * 64 + l;
@@ -617,7 +591,7 @@ struct AnceEncoder {
         _Float16 *h16, *qk16, *vt16, *ctx16, *ffn16;
         int4 *desc;              // attention descriptors in length-bucket order
         float *x32, *xa32, *qkv32, *ctx32, *ffn32;  // fp32 path only: hidden states, Q|K|V, attention output, FFN activation
-        float *part;             // folded LayerNorm: (mean, M2) of the 64-column slices of the last RES output
+        float *partA, *partB;    // folded LayerNorm: (mean, M2) of the twelve 64-column slices of every row of the two streams
         // folded LayerNorm: preA / preB hold the (hi, lo) fp16 pairs of the stream instead of fp32 rows
         _Float16 *xa_hi() const { return reinterpret_cast<_Float16 *>(preA); }
         _Float16 *xb_hi() const { return reinterpret_cast<_Float16 *>(preB); }
@@ -707,7 +681,8 @@ void layout_workspace(const AnceEncoderDesc *d, Arena &a, AnceEncoder *e) {
         L.vt16 = a.take<_Float16>((size_t)H * vcap);
         L.ctx16 = a.take<_Float16>((size_t)tcap * H);
         L.ffn16 = a.take<_Float16>((size_t)tcap * d->intermediate);
-        L.part = a.take<float>((size_t)tcap * (H / 64) * 2);
+        L.partA = a.take<float>((size_t)tcap * (H / 64) * 2);
+        L.partB = a.take<float>((size_t)tcap * (H / 64) * 2);
         L.x32 = L.xa32 = L.qkv32 = L.ctx32 = L.ffn32 = nullptr;
         if (precise_env()) {
             L.x32 = a.take<float>((size_t)tcap * H);
@@ -869,13 +844,13 @@ int encode_impl(AnceEncoder *e, const int32_t *base, int64_t ld, const int32_t *
                     float *dst = d_out + (size_t)(r0 * n_chunks + gs) * HEAD_OUT;
                     if (D.has_head) {
                         hipLaunchKernelGGL(head_gemm_kernel, dim3((S + 31) / 32, HEAD_OUT / 128), dim3(256), HEAD_LDS_BYTES, st, LN.preB,
-                                           (const _Float16 *)nullptr, (const _Float16 *)nullptr, LN.statsB, WL.ln2w, WL.ln2b, LN.seq_off, 0,
-                                           S, e->head_w, e->head_b, dst);
+                                           (const _Float16 *)nullptr, (const _Float16 *)nullptr, LN.statsB, (const float *)nullptr,
+                                           D.ln_eps, WL.ln2w, WL.ln2b, LN.seq_off, 0, S, e->head_w, e->head_b, dst);
                         hipLaunchKernelGGL(head_ln_kernel, dim3((S + 3) / 4), dim3(256), 0, st, dst, S, e->norm_w, e->norm_b);
                     } else {
                         hipLaunchKernelGGL(head_kernel, dim3(S), dim3(256), 0, st, LN.preB, (const _Float16 *)nullptr,
-                                           (const _Float16 *)nullptr, LN.statsB, WL.ln2w, WL.ln2b, LN.seq_off, 0, e->head_w, e->head_b,
-                                           e->norm_w, e->norm_b, 0, dst);
+                                           (const _Float16 *)nullptr, LN.statsB, (const float *)nullptr, D.ln_eps, WL.ln2w, WL.ln2b,
+                                           LN.seq_off, 0, e->head_w, e->head_b, e->norm_w, e->norm_b, 0, dst);
                     }
                 }
                 gs = g;
@@ -889,7 +864,7 @@ int encode_impl(AnceEncoder *e, const int32_t *base, int64_t ld, const int32_t *
             ProfScope pe(PC_EMBED, st);
             if (fold)
                 hipLaunchKernelGGL(embed_fold_kernel, dim3(Tpad / 4), dim3(256), 0, st, LN.tok_id, LN.tok_pos, Tpad, e->word, e->pos,
-                                   e->type0, D.vocab_size, D.max_position, D.ln_eps, xb_hi, xb_lo, LN.statsB);
+                                   e->type0, D.vocab_size, D.max_position, xb_hi, xb_lo, LN.partB);
             else
                 hipLaunchKernelGGL(embed_ln_kernel, dim3(Tpad / 4), dim3(256), 0, st, LN.tok_id, LN.tok_pos, Tpad, e->word, e->pos,
                                    e->type0, D.vocab_size, D.max_position, e->eln_w, e->eln_b, D.ln_eps, LN.preB, LN.h16, LN.statsB);
@@ -909,7 +884,7 @@ int encode_impl(AnceEncoder *e, const int32_t *base, int64_t ld, const int32_t *
                 G.A = fold ? xb_hi : LN.h16; G.lda = H; G.B = W.wqk; G.ldb = H; G.M = Tpad; G.N = 2 * H; G.K = H;
                 G.bias = W.bqk; G.out16 = LN.qk16; G.ldc = 2 * H; G.scale_cols = H;
                 G.scale = 0.125f * 1.44269504088896340736f;  // 1/sqrt(64) and log2(e): the softmax runs on exp2
-                G.row_stats = LN.statsB; G.csum = W.cqk;
+                G.part_in = LN.partB; G.ln_eps = D.ln_eps; G.csum = W.cqk;
                 int rc;
                 {
                     ProfScope ps(PC_GEMM_QK, st, 2.0 * T * (2.0 * H) * H);
@@ -920,7 +895,7 @@ int encode_impl(AnceEncoder *e, const int32_t *base, int64_t ld, const int32_t *
                 memset(&G, 0, sizeof(G));
                 G.A = W.wv; G.lda = H; G.B = fold ? xb_hi : LN.h16; G.ldb = H; G.M = H; G.N = Tpad; G.K = H;
                 G.bias = W.bv; G.out16 = LN.vt16; G.ldc = ldvt; G.col_map = LN.tok_vtcol; G.n_valid = T;
-                G.row_stats = LN.statsB; G.csum = W.cv;
+                G.part_in = LN.partB; G.ln_eps = D.ln_eps; G.csum = W.cv;
                 {
                     ProfScope ps(PC_GEMM_VT, st, 2.0 * T * (double)H * H);
                     rc = launch_gemm_f16(fold ? EPI_VT_F : EPI_VT, G, st);
@@ -941,16 +916,16 @@ int encode_impl(AnceEncoder *e, const int32_t *base, int64_t ld, const int32_t *
                 memset(&G, 0, sizeof(G));
                 G.res_stats = LN.statsB; G.res_gamma = rg; G.res_beta = rb;
                 if (fold) {
-                    G.res_hi = xb_hi; G.res_lo = xb_lo;
-                    if (tail) {  // compact (hi, lo, stats) rows of the [CLS] tokens, parked in the (currently dead) FFN buffer
+                    G.res_hi = xb_hi; G.res_lo = xb_lo; G.part_in = LN.partB; G.ln_eps = D.ln_eps;
+                    if (tail) {  // compact (hi, lo, partials) rows of the [CLS] tokens, parked in the (currently dead) FFN buffer
                         _Float16 *chi = LN.ffn16, *clo = chi + (size_t)S_pad * H;
-                        float *cst = reinterpret_cast<float *>(clo + (size_t)S_pad * H);
+                        float *cpt = reinterpret_cast<float *>(clo + (size_t)S_pad * H);
                         ProfScope ps(PC_LN, st);
-                        hipLaunchKernelGGL(gather_cls_fold_kernel, dim3(S_pad / 4), dim3(256), 0, st, xb_hi, xb_lo, LN.statsB, LN.seq_off,
-                                           S, S_pad, chi, clo, cst);
-                        G.res_hi = chi; G.res_lo = clo; G.res_stats = cst;
+                        hipLaunchKernelGGL(gather_cls_fold_kernel, dim3(S_pad / 4), dim3(256), 0, st, xb_hi, xb_lo, LN.partB, LN.seq_off,
+                                           S, S_pad, chi, clo, cpt);
+                        G.res_hi = chi; G.res_lo = clo; G.part_in = cpt;
                     }
-                    G.out16 = xa_hi; G.out_lo = xa_lo; G.part = LN.part;
+                    G.out16 = xa_hi; G.out_lo = xa_lo; G.part_out = LN.partA;
                 } else {
                     G.res32 = LN.preB;
                     if (tail) {  // compact residual rows (already normalised), parked in the (currently dead) FFN buffer
@@ -969,20 +944,16 @@ int encode_impl(AnceEncoder *e, const int32_t *base, int64_t ld, const int32_t *
                     rc = launch_gemm_f16(fold ? EPI_RESLN : EPI_RES32, G, st);
                 }
                 if (rc) return rc;
-                {
+                if (!fold) {
                     ProfScope ps(PC_LN, st);
-                    if (fold)
-                        hipLaunchKernelGGL(ln_finalize_kernel, dim3(Mrows / 256), dim3(256), 0, st, LN.part, H / 64, Mrows, D.ln_eps,
-                                           LN.statsA);
-                    else
-                        hipLaunchKernelGGL(ln_kernel, dim3(Mrows / 4), dim3(256), 0, st, LN.preA, Mrows, W.ln1w, W.ln1b, D.ln_eps,
-                                           LN.h16, LN.statsA);
+                    hipLaunchKernelGGL(ln_kernel, dim3(Mrows / 4), dim3(256), 0, st, LN.preA, Mrows, W.ln1w, W.ln1b, D.ln_eps,
+                                       LN.h16, LN.statsA);
                 }
                 // intermediate.dense + GELU
                 memset(&G, 0, sizeof(G));
                 G.A = fold ? xa_hi : LN.h16; G.lda = H; G.B = W.w1; G.ldb = H; G.M = Mrows; G.N = I; G.K = H;
                 G.bias = W.b1; G.out16 = LN.ffn16; G.ldc = I;
-                G.row_stats = LN.statsA; G.csum = W.c1;
+                G.part_in = LN.partA; G.ln_eps = D.ln_eps; G.csum = W.c1;
                 {
                     ProfScope ps(PC_GEMM_FFN1, st, 2.0 * Mwork * (double)I * H);
                     rc = launch_gemm_f16(fold ? EPI_GELU_F : EPI_GELU, G, st);
@@ -994,7 +965,8 @@ int encode_impl(AnceEncoder *e, const int32_t *base, int64_t ld, const int32_t *
                 G.bias = W.b2; G.ldc = H;
                 G.res_stats = LN.statsA; G.res_gamma = W.ln1w; G.res_beta = W.ln1b;
                 if (fold) {
-                    G.res_hi = xa_hi; G.res_lo = xa_lo; G.out16 = xb_hi; G.out_lo = xb_lo; G.part = LN.part;
+                    G.res_hi = xa_hi; G.res_lo = xa_lo; G.out16 = xb_hi; G.out_lo = xb_lo;
+                    G.part_in = LN.partA; G.ln_eps = D.ln_eps; G.part_out = LN.partB;
                 } else {
                     G.res32 = LN.preA; G.out32 = LN.preB;
                 }
@@ -1003,14 +975,10 @@ int encode_impl(AnceEncoder *e, const int32_t *base, int64_t ld, const int32_t *
                     rc = launch_gemm_f16(fold ? EPI_RESLN : EPI_RES32, G, st);
                 }
                 if (rc) return rc;
-                {
+                if (!fold) {
                     ProfScope ps(PC_LN, st);
-                    if (fold)
-                        hipLaunchKernelGGL(ln_finalize_kernel, dim3(Mrows / 256), dim3(256), 0, st, LN.part, H / 64, Mrows, D.ln_eps,
-                                           LN.statsB);
-                    else
-                        hipLaunchKernelGGL(ln_kernel, dim3(Mrows / 4), dim3(256), 0, st, LN.preB, Mrows, W.ln2w, W.ln2b, D.ln_eps,
-                                           LN.h16, LN.statsB);
+                    hipLaunchKernelGGL(ln_kernel, dim3(Mrows / 4), dim3(256), 0, st, LN.preB, Mrows, W.ln2w, W.ln2b, D.ln_eps,
+                                       LN.h16, LN.statsB);
                 }
             }
             {
@@ -1020,10 +988,12 @@ int encode_impl(AnceEncoder *e, const int32_t *base, int64_t ld, const int32_t *
                 const _Float16 *hh = fold ? xb_hi : nullptr, *hl = fold ? xb_lo : nullptr;
                 if (D.has_head && e->head_mfma) {
                     hipLaunchKernelGGL(head_gemm_kernel, dim3((S + 31) / 32, HEAD_OUT / 128), dim3(256), HEAD_LDS_BYTES, st, LN.preB, hh,
-                                       hl, LN.statsB, WL.ln2w, WL.ln2b, LN.seq_off, cls_tail ? 1 : 0, S, e->head_w, e->head_b, dst);
+                                       hl, LN.statsB, fold ? LN.partB : (const float *)nullptr, D.ln_eps, WL.ln2w, WL.ln2b, LN.seq_off,
+                                       cls_tail ? 1 : 0, S, e->head_w, e->head_b, dst);
                     hipLaunchKernelGGL(head_ln_kernel, dim3((S + 3) / 4), dim3(256), 0, st, dst, S, e->norm_w, e->norm_b);
                 } else {
-                    hipLaunchKernelGGL(head_kernel, dim3(S), dim3(256), 0, st, LN.preB, hh, hl, LN.statsB, WL.ln2w, WL.ln2b, LN.seq_off,
+                    hipLaunchKernelGGL(head_kernel, dim3(S), dim3(256), 0, st, LN.preB, hh, hl, LN.statsB,
+                                       fold ? LN.partB : (const float *)nullptr, D.ln_eps, WL.ln2w, WL.ln2b, LN.seq_off,
                                        cls_tail ? 1 : 0, e->head_w, e->head_b, e->norm_w, e->norm_b, D.has_head, dst);
                 }
             }

@@ -59,13 +59,41 @@ __device__ __forceinline__ void epi_sync() {
     }
 }
 
-// sum over the 16 lanes of a DPP row (the 16 lanes that cover one 64-float row segment in the read-back passes)
-__device__ __forceinline__ float row16_sum(float x) {
-    x += __builtin_amdgcn_update_dpp(0.f, x, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
-    x += __builtin_amdgcn_update_dpp(0.f, x, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
-    x += __builtin_amdgcn_update_dpp(0.f, x, 0x124, 0xF, 0xF, true);  // row_ror:4
-    x += __builtin_amdgcn_update_dpp(0.f, x, 0x128, 0xF, 0xF, true);  // row_ror:8
-    return x;
+// LDS-DMA of the epilogue parameter block (gemm_f16.h: EPB_*), issued by all 512 threads BEFORE the main loop: older
+// than every LDS-DMA of the pipeline, so the pipeline's first counted wait retires it and its first barrier publishes it.
+template <int EPI_>
+__device__ __forceinline__ void epb_issue(const GemmArgs &G, float *smem_f, int m0, int n0, int w, int l) {
+    typedef __attribute__((address_space(3))) void lds_t;
+    typedef const __attribute__((address_space(1))) void glb_t;
+    float *pb = smem_f + EPB_OFF;
+    const int tok0 = EPI_ == EPI_VT_F ? n0 : m0;  // first of the tile's 256 tokens
+    const float *psrc = G.part_in + (size_t)tok0 * 24;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int piece = w + 8 * j;  // 24 pieces of 1 KiB
+        __builtin_amdgcn_global_load_lds((glb_t *)(psrc + piece * 256 + l * 4), (lds_t *)(pb + EPB_PART + piece * 256), 16, 0, 0);
+    }
+    const int f0 = EPI_ == EPI_VT_F ? m0 : n0;    // first of the tile's 256 features
+    if (w == 0) __builtin_amdgcn_global_load_lds((glb_t *)(G.bias + f0 + l * 4), (lds_t *)(pb + EPB_VEC), 16, 0, 0);
+    if (EPI_ == EPI_RESLN) {
+        if (w == 1) __builtin_amdgcn_global_load_lds((glb_t *)(G.res_gamma + f0 + l * 4), (lds_t *)(pb + EPB_VEC + 256), 16, 0, 0);
+        if (w == 2) __builtin_amdgcn_global_load_lds((glb_t *)(G.res_beta + f0 + l * 4), (lds_t *)(pb + EPB_VEC + 512), 16, 0, 0);
+    } else {
+        if (w == 1) __builtin_amdgcn_global_load_lds((glb_t *)(G.csum + f0 + l * 4), (lds_t *)(pb + EPB_VEC + 256), 16, 0, 0);
+    }
+}
+
+// first step of a folded epilogue (all 512 threads, after the main loop): thread t < 256 combines the slice partials of
+// token t into (mean, rstd); one workgroup barrier publishes them
+__device__ __forceinline__ void epb_stats(const GemmArgs &G, float *smem_f, int tid) {
+    float *pb = smem_f + EPB_OFF;
+    if (tid < 256) {
+        float mean, rstd;
+        stats_from_parts(pb + EPB_PART + tid * 24, G.ln_eps, &mean, &rstd);
+        pb[EPB_STATS + 2 * tid] = mean;
+        pb[EPB_STATS + 2 * tid + 1] = rstd;
+    }
+    __syncthreads();
 }
 
 template <int EPI_, bool WAVE_SYNC = false>
@@ -94,9 +122,13 @@ __device__ __forceinline__ void gemm256_epilogue(const GemmArgs &G, f32x16 (&acc
             epi_sync<WAVE_SYNC>();
 #pragma unroll
             for (int yy = 0; yy < 2; ++yy) {
-                const float bias = G.bias[mw0 + (2 * p + yy) * 32 + i];
-                float cs = 0.f;
-                if constexpr (FOLD) cs = G.csum[mw0 + (2 * p + yy) * 32 + i];
+                float bias, cs = 0.f;
+                if constexpr (FOLD) {
+                    bias = smem_f[EPB_OFF + EPB_VEC + wm * 128 + (2 * p + yy) * 32 + i];
+                    cs = smem_f[EPB_OFF + EPB_VEC + 256 + wm * 128 + (2 * p + yy) * 32 + i];
+                } else {
+                    bias = G.bias[mw0 + (2 * p + yy) * 32 + i];
+                }
 #pragma unroll
                 for (int x = 0; x < 2; ++x)
 #pragma unroll
@@ -104,7 +136,7 @@ __device__ __forceinline__ void gemm256_epilogue(const GemmArgs &G, f32x16 (&acc
                         const f32x16 &a = acc[x][2 * p + yy];
                         f32x4 t = f32x4{a[4 * rq], a[4 * rq + 1], a[4 * rq + 2], a[4 * rq + 3]};
                         if constexpr (FOLD) {  // tokens are the columns: (mean, rstd) of 4 consecutive tokens = 32 bytes
-                            const float *sp = G.row_stats + 2 * (size_t)(nw0 + x * 32 + 8 * rq + 4 * g);
+                            const float *sp = smem_f + EPB_OFF + EPB_STATS + 2 * (wn * 64 + x * 32 + 8 * rq + 4 * g);
                             const f32x4 s01 = *reinterpret_cast<const f32x4 *>(sp);
                             const f32x4 s23 = *reinterpret_cast<const f32x4 *>(sp + 4);
                             t[0] = (t[0] - s01[0] * cs) * s01[1];
@@ -177,13 +209,14 @@ __device__ __forceinline__ void gemm256_epilogue(const GemmArgs &G, f32x16 (&acc
         // as EPI_RES32, with the residual stream as an fp16 pair: v = acc + bias + LayerNorm(res_hi + res_lo);
         // out16 = fp16(v) (the next GEMM's token operand AND the high half of the stream), out_lo = fp16(v - out16)
         // (v - fp16(v) is exact in fp32; the pair carries 22 bits).  Per row and 64-column slice the (mean, M2) of v go
-        // to part[] -- ln_finalize_kernel combines the N / 64 slices of a row (Chan) into (mean, rstd).
+        // to part_out[] -- the consumers combine the N / 64 slices of a row (Chan) into (mean, rstd) in their own epilogues.
         float *slab = smem_f + w * 4096;
         constexpr int LS = 68;
         const int c4 = l & 15;
-        const f32x4 bias = *reinterpret_cast<const f32x4 *>(G.bias + nw0 + c4 * 4);
-        const f32x4 lng = *reinterpret_cast<const f32x4 *>(G.res_gamma + nw0 + c4 * 4);
-        const f32x4 bias_beta = bias + *reinterpret_cast<const f32x4 *>(G.res_beta + nw0 + c4 * 4);
+        const float *pb = smem_f + EPB_OFF;
+        const f32x4 lng = *reinterpret_cast<const f32x4 *>(pb + EPB_VEC + 256 + wn * 64 + c4 * 4);
+        const f32x4 bias_beta = *reinterpret_cast<const f32x4 *>(pb + EPB_VEC + wn * 64 + c4 * 4) +
+                                *reinterpret_cast<const f32x4 *>(pb + EPB_VEC + 512 + wn * 64 + c4 * 4);
         const int n_parts = G.N >> 6, slice = nw0 >> 6;
 #pragma unroll
         for (int y = 0; y < 4; ++y) {
@@ -195,8 +228,8 @@ __device__ __forceinline__ void gemm256_epilogue(const GemmArgs &G, f32x16 (&acc
                 const size_t row = (size_t)(mw0 + y * 32 + rr);
                 rh[it] = *reinterpret_cast<const f16x4 *>(G.res_hi + row * G.ldc + nw0 + c4 * 4);
                 rl[it] = *reinterpret_cast<const f16x4 *>(G.res_lo + row * G.ldc + nw0 + c4 * 4);
-                mean[it] = G.res_stats[2 * row];
-                rstd[it] = G.res_stats[2 * row + 1];
+                mean[it] = pb[EPB_STATS + 2 * (wm * 128 + y * 32 + rr)];
+                rstd[it] = pb[EPB_STATS + 2 * (wm * 128 + y * 32 + rr) + 1];
             }
             epi_sync<WAVE_SYNC>();
 #pragma unroll
@@ -230,7 +263,7 @@ __device__ __forceinline__ void gemm256_epilogue(const GemmArgs &G, f32x16 (&acc
                 const float d0 = v[0] - m64, d1 = v[1] - m64, d2 = v[2] - m64, d3 = v[3] - m64;
                 const float q64 = row16_sum((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3));
                 if (c4 == 0) {
-                    float *pp = G.part + (row * n_parts + slice) * 2;
+                    float *pp = G.part_out + (row * n_parts + slice) * 2;
                     pp[0] = m64;
                     pp[1] = q64;
                 }
@@ -250,7 +283,7 @@ __device__ __forceinline__ void gemm256_epilogue(const GemmArgs &G, f32x16 (&acc
             for (int yy = 0; yy < 2; ++yy) {
                 float mu = 0.f, rs = 1.f;
                 if constexpr (FOLD) {  // tokens are the rows: one (mean, rstd) per lane and 32-row block
-                    const float *sp = G.row_stats + 2 * (size_t)(mw0 + (2 * p + yy) * 32 + i);
+                    const float *sp = smem_f + EPB_OFF + EPB_STATS + 2 * (wm * 128 + (2 * p + yy) * 32 + i);
                     mu = sp[0];
                     rs = sp[1];
                 }
@@ -260,11 +293,14 @@ __device__ __forceinline__ void gemm256_epilogue(const GemmArgs &G, f32x16 (&acc
                     for (int rq = 0; rq < 4; ++rq) {
                         const f32x16 &a = acc[x][2 * p + yy];
                         const int nl = x * 32 + 8 * rq + 4 * g;  // local n of element 0
-                        const f32x4 bias = *reinterpret_cast<const f32x4 *>(G.bias + nw0 + nl);
+                        f32x4 bias;
                         f32x4 t = f32x4{a[4 * rq], a[4 * rq + 1], a[4 * rq + 2], a[4 * rq + 3]};
                         if constexpr (FOLD) {
-                            const f32x4 cs = *reinterpret_cast<const f32x4 *>(G.csum + nw0 + nl);
+                            bias = *reinterpret_cast<const f32x4 *>(smem_f + EPB_OFF + EPB_VEC + wn * 64 + nl);
+                            const f32x4 cs = *reinterpret_cast<const f32x4 *>(smem_f + EPB_OFF + EPB_VEC + 256 + wn * 64 + nl);
                             t = (t - mu * cs) * rs;
+                        } else {
+                            bias = *reinterpret_cast<const f32x4 *>(G.bias + nw0 + nl);
                         }
                         t = t + bias;
                         if constexpr (EPI == EPI_GELU) {

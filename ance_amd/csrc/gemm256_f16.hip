@@ -175,7 +175,10 @@ __global__ void __launch_bounds__(G256_THREADS, 2) gemm256_f16_desc_kernel(const
             P.S.voff[h][j] = (uint32_t)(pipe_a_tile_row(h, r) * G.lda + ch) * 2u;
             P.S.voff[2 + h][j] = (uint32_t)(pipe_b_tile_row(h, r) * G.ldb + ch) * 2u;
         }
+    constexpr bool EPB = EPI >= EPI_RESLN;  // folded-LayerNorm epilogues: parameter block by LDS-DMA, ahead of the pipeline's own
+    if constexpr (EPB) epb_issue<EPI>(G, smem_f, m0, n0, w, l);
     P.run(G.K / TK, acc);
+    if constexpr (EPB) epb_stats(G, smem_f, tid);
     gemm256_epilogue<EPI, true>(G, acc, smem_f, m0, n0, w, l);
 }
 
@@ -283,11 +286,12 @@ int launch256(int epi, const GemmArgs &G, hipStream_t st) {
     const unsigned long long dbit = 1ull << (dev & 63);
     if (!(attr_done[ai] & dbit)) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)G256_LDS_BYTES) != hipSuccess)
+                                (int)(G256_LDS_BYTES + (size_t)EPB_FLOATS * sizeof(float))) != hipSuccess)
             return check_launch("gemm256 attr");
         attr_done[ai] |= dbit;
     }
-    hipLaunchKernelGGL(k, dim3(blocks), dim3(G256_THREADS), G256_LDS_BYTES, st, G);
+    const size_t lds = epi >= EPI_RESLN ? G256_LDS_BYTES + (size_t)EPB_FLOATS * sizeof(float) : G256_LDS_BYTES;
+    hipLaunchKernelGGL(k, dim3(blocks), dim3(G256_THREADS), lds, st, G);
     return ANCE_OK;
 }
 
