@@ -124,8 +124,18 @@ __global__ void __launch_bounds__(256) idx_mean_kernel(const float *part, int n_
 struct QueryStat {
     float mq_norm;  // |mq| (0 when not used)
     int use_bias;   // != 0: dq = q - mq goes through the MFMAs, b = mq . x' is added per row
+    int bad_image;  // != 0: the image's stamp does not match this call: no kernel touches it, every chunk is redone exactly
 };
-__global__ void __launch_bounds__(256) query_mean_decide_kernel(float *mq, int d, const DedupHeader *H, QueryStat *qs) {
+__global__ void __launch_bounds__(64) idx_stamp_kernel(DedupHeader *H, int64_t n, int d, const float *x) {
+    if (threadIdx.x == 0) {
+        H->d = (unsigned int)d;
+        H->n = (unsigned long long)n;
+        H->x_ptr = (unsigned long long)(uintptr_t)x;
+        H->magic = DEDUP_MAGIC;
+    }
+}
+__global__ void __launch_bounds__(256) query_mean_decide_kernel(float *mq, int d, const DedupHeader *H, QueryStat *qs, int64_t n,
+                                                                const float *x) {
     __shared__ float red[4];
     float s = 0.f;
     for (int c = threadIdx.x; c < d; c += 256) s += mq[c] * mq[c];
@@ -135,13 +145,16 @@ __global__ void __launch_bounds__(256) query_mean_decide_kernel(float *mq, int d
     __syncthreads();
     const float nrm = sqrtf(red[0] + red[1] + red[2] + red[3]) * 1.0001f;
     const float xo = __builtin_bit_cast(float, H->xmax_orig_bits);
-    const bool use = nrm == nrm && nrm < 3.0e38f && xo < 3.0e38f && nrm > 0.05f * xo;
+    const bool bad = H->magic != DEDUP_MAGIC || H->d != (unsigned int)d || H->n != (unsigned long long)n ||
+                     H->x_ptr != (unsigned long long)(uintptr_t)x;
+    const bool use = !bad && nrm == nrm && nrm < 3.0e38f && xo < 3.0e38f && nrm > 0.05f * xo;
     __syncthreads();
     if (!use)
         for (int c = threadIdx.x; c < d; c += 256) mq[c] = 0.0f;
     if (threadIdx.x == 0) {
         qs->mq_norm = use ? nrm : 0.0f;
         qs->use_bias = use ? 1 : 0;
+        qs->bad_image = bad ? 1 : 0;
     }
 }
 
@@ -586,7 +599,7 @@ __device__ __forceinline__ int prune_list(u64 *cq, int n_c, int lp, int k, float
 // choice needs no host synchronisation, and the common case keeps the leaner kernel (the bias build is ~5 % slower).
 template <bool STAMPS, bool BIAS>
 __global__ void __launch_bounds__(F_THREADS, 2) ip_topk_fast_kernel(const FastParams P) {
-    if ((P.qstat->use_bias != 0) != BIAS) return;
+    if ((P.qstat->use_bias != 0) != BIAS || P.qstat->bad_image) return;
     extern __shared__ __attribute__((aligned(16))) float smem_f[];
     _Float16 *smem = reinterpret_cast<_Float16 *>(smem_f);
     float *thr_s = smem_f + (2 * F_STAGE_HALVES) / 2;  // after the 128 KiB of stages: filter threshold t~ - 2 eps
@@ -919,6 +932,7 @@ inline size_t rescore_lds_bytes(int d) { return ((size_t)d + F_C / 2 + 64 * RS_S
 
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) rescore_kernel(const RescoreParams P) {  // LDS allows 2 waves per CU
     extern __shared__ __attribute__((aligned(16))) float rs_smem[];
+    if (P.qstat->bad_image) return;
     const int l = threadIdx.x;
     const int d = P.d;
     float *qrow_lds = rs_smem;                                                   // d floats
@@ -1045,8 +1059,15 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
 }
 
 // after the filter launch: turn the overflow list into the input of the per-query exact scan
-__global__ void __launch_bounds__(256) gather_overflow_kernel(FastCtl *ctl, const int *ovf_list, const float *q32, int d, float *qfb,
-                                                              int *fb_slot) {
+__global__ void __launch_bounds__(256) gather_overflow_kernel(FastCtl *ctl, const QueryStat *qs, const int *ovf_list, const float *q32,
+                                                              int d, float *qfb, int *fb_slot) {
+    if (qs->bad_image) {  // nothing was filtered: the whole chunk goes to the exact scan
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            ctl->fb_all = 1;
+            ctl->fb_nq = 0;
+        }
+        return;
+    }
     const int cnt = ctl->ovf_count;
     if (cnt == 0) return;
     const int i = blockIdx.x;
@@ -1198,6 +1219,7 @@ int ip_index_build(const float *d_x, int64_t n, int d, void *d_index, size_t ind
     }
     hipLaunchKernelGGL(idx_compact_round_kernel, dim3((unsigned)L.nb), dim3(256), 0, st, d_x, n, d, L.nb, H, cls, blk, mu, x2,
                        live2row, members);
+    hipLaunchKernelGGL(idx_stamp_kernel, dim3(1), dim3(64), 0, st, H, n, d, d_x);  // last: marks the build complete
     return check_launch("ance_ip_index_build");
 }
 
@@ -1286,7 +1308,7 @@ int ip_topk_fast(const float *d_x, int64_t n, int64_t row_base, const void *d_in
         hipLaunchKernelGGL(idx_colsum_kernel, dim3((unsigned)n_part_q), dim3(256), 0, st, d_q, nq, d, qpart);
         hipLaunchKernelGGL(idx_mean_kernel, dim3((unsigned)((d + 255) / 256)), dim3(256), 0, st, qpart, n_part_q, nq, d,
                            fast_knobs().center, mq);
-        hipLaunchKernelGGL(query_mean_decide_kernel, dim3(1), dim3(256), 0, st, mq, d, reinterpret_cast<const DedupHeader *>(ib), qstat);
+        hipLaunchKernelGGL(query_mean_decide_kernel, dim3(1), dim3(256), 0, st, mq, d, reinterpret_cast<const DedupHeader *>(ib), qstat, n, d_x);
         (void)hipMemsetAsync(bias, 0, pl.bias_bytes, st);
         hipLaunchKernelGGL(row_bias_kernel, dim3(4096), dim3(256), 0, st, d_x, d, reinterpret_cast<const DedupHeader *>(ib),
                            reinterpret_cast<const uint32_t *>(ib + Li.live_off), reinterpret_cast<const float *>(ib + Li.mu_off), mq,
@@ -1346,7 +1368,7 @@ int ip_topk_fast(const float *d_x, int64_t n, int64_t row_base, const void *d_in
             hipLaunchKernelGGL(rescore_kernel, dim3((unsigned)(P.n_qt * pl.S * FQ)), dim3(64), rescore_lds_bytes(d), st, R);
         }
         // queries whose buffers overflowed: redone by the exact scan, one by one (<= OVF_CAP) or as a whole chunk
-        hipLaunchKernelGGL(gather_overflow_kernel, dim3(OVF_CAP), dim3(256), 0, st, ctl, ovf_list, d_q + (size_t)q0 * d, d, qfb, fb_slot);
+        hipLaunchKernelGGL(gather_overflow_kernel, dim3(OVF_CAP), dim3(256), 0, st, ctl, qstat, ovf_list, d_q + (size_t)q0 * d, d, qfb, fb_slot);
         const u64 *fb_part = nullptr, *fball_part = nullptr;
         int fb_m = 0, fball_m = 0;
         int rc = exact_scan_fallback(d_x, n, qfb, OVF_CAP, OVF_CAP, d, k, fb_ws, nullptr, &ctl->fb_nq, &fb_part, &fb_m, st);

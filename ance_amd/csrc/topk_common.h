@@ -76,7 +76,13 @@ struct DedupHeader {                // first 256 bytes of a search image
     unsigned int guess[DEDUP_MAXC]; // sampled row that defines the class
     unsigned int rep[DEDUP_MAXC];   // smallest row id of the class: stays in the image
     unsigned int csize[DEDUP_MAXC]; // members besides the representative
+    // stamp of a COMPLETED build: which matrix this image belongs to.  A search whose (n, d, rows pointer) do not match --
+    // an image of another shard, a buffer that was never built -- is answered by the exact scan instead of gathering rows
+    // through someone else's live2row (include/ance_amd.h: ance_ip_topk_indexed)
+    unsigned int magic, d;
+    unsigned long long n, x_ptr;
 };
+constexpr unsigned int DEDUP_MAGIC = 0x414E4345u;  // "ANCE"
 
 // where topk_finalize takes a query's survivors from when the fast path handed the query (or its whole launch
 // chunk) to the exact scan, and the duplicate classes to expand otherwise

@@ -101,6 +101,9 @@ int ance_ip_topk(const float *d_x, int64_t n, int64_t row_base, const float *d_q
  *   bytes = ance_ip_index_bytes(n, d)        0: the shape has no image (the scan is used), pass NULL
  *   ance_ip_index_build(d_x, n, d, d_index, bytes, stream)
  *   ance_ip_topk_indexed(d_x, n, row_base, d_index, ...)   with ance_ip_topk_indexed_workspace_bytes
+ * The image is stamped with the (n, d, d_x) it was built from when the build completes; a search whose arguments do not
+ * match the stamp -- another shard's image, a buffer never built -- ignores the image on the device (no host
+ * synchronisation) and answers every query with the exact scan: slower, never wrong rows.
  * The image is valid for exactly the (d_x, n, d) it was built from; d_x must stay alive and unchanged
  * (the exact re-scoring reads the fp32 rows).  Contents: the shard's mean row, fp16(row - mean) for every
  * row kept (n d 2 bytes), row map, duplicate classes.  Results are those of ance_ip_topk, bit for bit.

@@ -576,3 +576,45 @@ def test_two_towers_with_different_common_components():
     _check_exact("two_towers_few", x, q[:3], 200)
     from oracle import synth
     _check_exact("common_rows_ln_queries", x, synth.ln_rows(rng, 90), 50)
+
+
+def test_image_of_another_matrix_is_not_trusted():
+    """A search image carries the stamp of the matrix it was built from (n, d, rows pointer).  Handed to a search over
+    other rows -- here: same shape, another tensor -- the library must not filter through it (stale fp16 rows, someone
+    else's live2row): every query is answered by the exact scan, same bits as the oracle (the C entry point
+    used to trust d_index completely)."""
+    import ctypes
+    import torch
+    from ance_amd import _lib
+    from ance_amd.index import FlatIPIndex
+    from oracle import search_ref, synth
+    rng = np.random.default_rng(61)
+    x1, x2 = synth.ln_rows(rng, 20000), synth.ln_rows(rng, 20000)
+    q = synth.ln_rows(rng, 70)
+    idx = FlatIPIndex(768)
+    idx.add(x1)
+    idx.search(q, 50)                          # builds the image of x1
+    img = idx._image
+    assert img is not None and img is not False
+    x2d = torch.from_numpy(x2).cuda()
+    qd = torch.from_numpy(q).cuda()
+    L = _lib.lib()
+    n, k = 20000, 50
+    D = torch.empty((70, k), dtype=torch.float32, device="cuda")
+    I = torch.empty((70, k), dtype=torch.int64, device="cuda")
+    ws = torch.empty(L.ance_ip_topk_indexed_workspace_bytes(n, 70, 768, k), dtype=torch.uint8, device="cuda")
+    rc = L.ance_ip_topk_indexed(ctypes.c_void_p(x2d.data_ptr()), n, 0, ctypes.c_void_p(img.data_ptr()), ctypes.c_void_p(qd.data_ptr()),
+                                70, 768, k, ctypes.c_void_p(D.data_ptr()), ctypes.c_void_p(I.data_ptr()), ctypes.c_void_p(ws.data_ptr()),
+                                ws.numel(), _lib.current_stream_ptr())
+    _lib.check(rc, "ance_ip_topk_indexed")
+    torch.cuda.synchronize()
+    Do, Io = search_ref.flat_ip_topk_chain(x2, q, k)
+    assert np.array_equal(I.cpu().numpy(), Io) and np.array_equal(D.cpu().numpy(), Do)
+    # a buffer that was never built (all zero) is refused the same way
+    blank = torch.zeros_like(img)
+    rc = L.ance_ip_topk_indexed(ctypes.c_void_p(x2d.data_ptr()), n, 0, ctypes.c_void_p(blank.data_ptr()), ctypes.c_void_p(qd.data_ptr()),
+                                70, 768, k, ctypes.c_void_p(D.data_ptr()), ctypes.c_void_p(I.data_ptr()), ctypes.c_void_p(ws.data_ptr()),
+                                ws.numel(), _lib.current_stream_ptr())
+    _lib.check(rc, "ance_ip_topk_indexed")
+    torch.cuda.synchronize()
+    assert np.array_equal(I.cpu().numpy(), Io) and np.array_equal(D.cpu().numpy(), Do)
