@@ -218,6 +218,24 @@ def random_init_roberta_base(torch, n_layers, seed=0):
     return sd
 
 
+CURRENT_ROUND = "r03"  # counters and kernel traces under profiles/ are quoted only when they were taken on this round's tree
+KERNEL_OF = {"gemm_ffn1": "gemm256_f16_desc_kernel<6>", "gemm_qk": "gemm256_f16_desc_kernel<5>", "gemm_vt": "gemm256_f16_desc_kernel<7>",
+             "gemm_attn_out": "gemm256_f16_desc_kernel<4>", "gemm_ffn2": "gemm256_f16_desc_kernel<4>"}
+
+
+def trace_avg_ns(csv_name, needle):
+    """AverageNs of the kernel whose name contains `needle` in a committed rocprofv3 --stats CSV (None if absent)."""
+    import csv
+    try:
+        with open(os.path.join(ROOT, "profiles", csv_name)) as f:
+            for row in csv.DictReader(f):
+                if needle in row["Name"]:
+                    return float(row["AverageNs"])
+    except Exception:
+        pass
+    return None
+
+
 def pmc_traffic(leg, kernel):
     """HBM bytes per launch of the dominant kernel from rocprofv3 PMC passes (FETCH_SIZE x2 for wide
     reads on gfx950 + WRITE_SIZE, MI355X_MICROARCH.md HBM section).  PMC cannot be collected from
@@ -225,7 +243,8 @@ def pmc_traffic(leg, kernel):
     scripts/gpu_pmc.sh regenerates on the same workload (null if the file has no entry)."""
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-            return json.load(f).get(leg, {}).get(kernel)
+            ent = json.load(f).get(leg, {}).get("gemm_res" if kernel in ("gemm_attn_out", "gemm_ffn2") else kernel)
+        return ent if ent and str(ent.get("round", "")).startswith(CURRENT_ROUND) else None  # never quote another round's counters
     except Exception:
         return None
 
@@ -427,8 +446,14 @@ def main():
             ach = prof[dom]["work"] / (prof[dom]["ms"] * 1e-3) / 1e12 if prof[dom]["ms"] > 0 else None
             all_gemm_ms = sum(prof[c]["ms"] for c in gemm_cats)
             all_gemm_work = sum(prof[c]["work"] for c in gemm_cats)
-            out["roofline"] = {"bound": "mfma", "kernel": "gemm256_f16_desc_kernel (%s)" % dom, "achieved": ach, "peak": PEAK_F16_TF,
-                               "unit": "TFLOP/s", "frac": (ach / PEAK_F16_TF) if ach else None, "traffic": pmc_traffic("encode", dom),
+            # the same fraction from the committed kernel trace of this round (profiles/): FLOPs of one launch / its average
+            # duration in the single-stream rocprofv3 --stats CSV
+            t_ns = trace_avg_ns("%s_rocprofv3_encode_single_stream_kernel_stats.csv" % CURRENT_ROUND, KERNEL_OF.get(dom, "?"))
+            flop_launch = prof[dom]["work"] / max(prof[dom]["count"], 1)
+            out["roofline"] = {"bound": "mfma", "kernel": "%s (%s)" % (KERNEL_OF.get(dom, "gemm256_f16_desc_kernel"), dom), "achieved": ach,
+                               "peak": PEAK_F16_TF, "unit": "TFLOP/s", "frac": (ach / PEAK_F16_TF) if ach else None,
+                               "frac_from_profiles": (flop_launch / (t_ns * 1e-9) / 1e12 / PEAK_F16_TF) if t_ns else None,
+                               "traffic": pmc_traffic("encode", dom),
                                "timing": "HIP events on the launch stream, single-stream pass of the same %d steps "
                                          "(%.1f ms/step isolated vs %.1f ms/step overlapped)" % (a.steps, 1e3 * dt_iso / a.steps, 1e3 * dt / a.steps),
                                "all_gemm_tflops": all_gemm_work / (all_gemm_ms * 1e-3) / 1e12 if all_gemm_ms > 0 else None,
@@ -535,7 +560,11 @@ def main():
                                           "kernel": "ip_topk_fast_kernel (fp16 MFMA 32x32x16 filter; algorithmic FLOPs = 2 nq n d = "
                                                     "1,536 per query-row pair)",
                                           "achieved": ach, "peak": PEAK_F16_TF, "unit": "TFLOP/s",
-                                          "frac": (ach / PEAK_F16_TF) if ach else None, "traffic": traffic,
+                                          "frac": (ach / PEAK_F16_TF) if ach else None,
+                                          "frac_from_profiles": (lambda t_: (2.0 * a.query_block * n_loc * 768 / (t_ * 1e-9) / 1e12 / PEAK_F16_TF)
+                                                                 if t_ and world == 1 else None)(
+                                              trace_avg_ns("%s_rocprofv3_search_kernel_stats.csv" % CURRENT_ROUND, "ip_topk_fast_kernel<false, false>")),
+                                          "traffic": traffic,
                                           "ms_per_launch": scan["ms"] / n_scan,
                                           "rescore_ms_per_launch": resc["ms"] / max(resc["count"], 1),
                                           "rescore_kernel": "rescore_kernel (exact fp32 fmaf chains of the ~k + 66 band rows per query, shared between its split lists; "

@@ -7,20 +7,23 @@ set -u
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out/pmc
 export TMPDIR=/tmp
-S="python bench.py --skip-encode --no-cpu-baseline --steps ${PMC_STEPS:-2} --warmup 1"
-E="python bench.py --skip-search --no-cpu-baseline --steps ${PMC_STEPS:-2} --warmup 1"
+# one step, no fp32-mode sample, no second search leg, and counters only for the kernels a roofline is reported for: a pass
+# of the encode leg (~6 k dispatches) otherwise does not finish inside the 900 s limit
+S="python bench.py --skip-encode --no-cpu-baseline --skip-encoder-like --steps ${PMC_STEPS:-1} --warmup 1"
+E="python bench.py --skip-search --no-cpu-baseline --skip-precise --steps ${PMC_STEPS:-1} --warmup 1"
 for what in ${PMC_LEGS:-search encode}; do
   cmd="$S"; [ $what = encode ] && cmd="$E"
   [ $what = encode ] && export ANCE_ENCODER_STREAMS=1
+  rx="ip_topk_fast_kernel|rescore_kernel"; [ $what = encode ] && rx="gemm256_f16_desc_kernel|attention_kernel"
   echo "== kernel-trace $what"
   timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/pmc/kt_$what -o kt -- $cmd > gpurun_out/pmc/kt_$what.log 2>&1; echo "rc=$?"
   echo "== pmc cycles $what (GRBM_GUI_ACTIVE = shader clocks of the dispatch: clock-independent cost, and the clock itself)"
-  timeout 900 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES --kernel-trace --output-format csv -d gpurun_out/pmc/CYCLES_$what -o pmc -- $cmd > gpurun_out/pmc/CYCLES_$what.log 2>&1; echo "rc=$?"
+  timeout 900 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES --kernel-trace --kernel-include-regex "$rx" --output-format csv -d gpurun_out/pmc/CYCLES_$what -o pmc -- $cmd > gpurun_out/pmc/CYCLES_$what.log 2>&1; echo "rc=$?"
   echo "== pmc L2 hit/miss $what"
-  timeout 900 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d gpurun_out/pmc/L2_$what -o pmc -- $cmd > gpurun_out/pmc/L2_$what.log 2>&1; echo "rc=$?"
+  timeout 900 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --kernel-trace --kernel-include-regex "$rx" --output-format csv -d gpurun_out/pmc/L2_$what -o pmc -- $cmd > gpurun_out/pmc/L2_$what.log 2>&1; echo "rc=$?"
   for c in FETCH_SIZE WRITE_SIZE; do
     echo "== pmc $c $what"
-    timeout 900 rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmc/${c}_$what -o pmc -- $cmd > gpurun_out/pmc/${c}_$what.log 2>&1; echo "rc=$?"
+    timeout 900 rocprofv3 --pmc $c --kernel-trace --kernel-include-regex "$rx" --output-format csv -d gpurun_out/pmc/${c}_$what -o pmc -- $cmd > gpurun_out/pmc/${c}_$what.log 2>&1; echo "rc=$?"
     tail -2 gpurun_out/pmc/${c}_$what.log | cut -c1-200
   done
   unset ANCE_ENCODER_STREAMS

@@ -96,9 +96,11 @@ if len(sys.argv) > 2:
         return (sum(dur) / len(dur), len(dur)) if dur else (None, 0)
 
     out = {}
-    for leg, cat, needle in (("encode", "gemm_ffn1", "gemm256_f16_desc_kernel<1"), ("encode", "gemm_qk", "gemm256_f16_desc_kernel<0"),
-                             ("encode", "gemm_res32", "gemm256_f16_desc_kernel<2"), ("encode", "gemm_vt", "gemm256_f16_desc_kernel<3"),
-                             ("encode", "layernorm", "ln_kernel"), ("encode", "attention", "attention_kernel"),
+    # template arguments of gemm256_f16_desc_kernel: gemm_f16.h (4 = RESLN: attention.output.dense and output.dense, 5 = QK_F,
+    # 6 = GELU_F: intermediate.dense, 7 = VT_F)
+    for leg, cat, needle in (("encode", "gemm_ffn1", "gemm256_f16_desc_kernel<6"), ("encode", "gemm_qk", "gemm256_f16_desc_kernel<5"),
+                             ("encode", "gemm_res", "gemm256_f16_desc_kernel<4"), ("encode", "gemm_vt", "gemm256_f16_desc_kernel<7"),
+                             ("encode", "attention", "attention_kernel"),
                              ("search", "ip_topk_fast", "ip_topk_fast_kernel<false, false>"), ("search", "ip_topk_rescore", "rescore_kernel"),
                              ("search", "ip_topk_scan", "ip_topk_scan_kernel")):
         fe, wr = per_dispatch(leg, "FETCH_SIZE", needle), per_dispatch(leg, "WRITE_SIZE", needle)
@@ -108,6 +110,7 @@ if len(sys.argv) > 2:
         out.setdefault(leg, {})[cat] = {"cycles": cycles(leg, needle), "l2_hit_rate": l2_hit(leg, needle),
                                         "kernel_trace_avg_ns": avg_ns, "kernel_trace_dispatches": n_disp,
                                         "hbm_bytes_per_launch": 2.0 * fe + wr, "fetch_bytes_x2": 2.0 * fe, "write_bytes": wr,
+                                        "round": os.environ.get("ANCE_ROUND", "r03"),
                                         "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / TCC_HIT,MISS / cycles (separate passes) on the bench.py leg "
                                                 "itself (scripts/gpu_pmc.sh); FETCH_SIZE doubled per MI355X_MICROARCH.md (wide reads on gfx950)"}
     with open(sys.argv[2], "w") as f:
