@@ -176,7 +176,18 @@ typedef struct AnceEncoder AnceEncoder;
 #define ANCE_ENCODER_N_WEIGHTS(n_layers, has_head) (5 + 16 * (n_layers) + ((has_head) ? 4 : 0))
 
 /* Bytes of the packed weight arena (fp16 GEMM operands + fp32 vectors) and of the activation
- * workspace for desc->max_tokens.  Both are caller-allocated device buffers, 256-byte aligned. */
+ * workspace for desc->max_tokens.  Both are caller-allocated device buffers, 256-byte aligned.
+ *
+ * Arithmetic.  Default: fp16 MFMA operands, fp32 accumulation, fp32 softmax / statistics / head; LayerNorm folded into the
+ * GEMMs and the residual stream kept as fp16 (hi, lo) pairs (22 mantissa bits) -- max |delta| 3e-3 on unit-variance
+ * embeddings against the reference's fp32 arithmetic (stated tolerance of the tests: 5e-3).
+ * Environment, read when a handle is created (the two size queries read ANCE_ENCODER_PRECISE as well):
+ *   ANCE_ENCODER_PRECISE=1   fp32 mode: fp32 operands on the fp32-input matrix cores, exact erf GELU, fp32 softmax -- the
+ *                            reference's arithmetic (model/models.py:149-157); max |delta| 1e-5, ~9 x slower
+ *   ANCE_ENCODER_STREAMS=n   internal streams / activation sets (1..4, default 2)
+ *   ANCE_LN_FOLD=0 ANCE_HEAD_MFMA=0 ANCE_CLS_TAIL=0 ANCE_ATTN_COAL=0 ANCE_GEMM_DESC=0   A/B switches back to the previous
+ *                            form of one piece each (LayerNorm kernels, per-sequence head, full last layer, per-lane
+ *                            attention loads / stores, flat-pointer GEMM staging) */
 size_t ance_encoder_weight_bytes(const AnceEncoderDesc *desc);
 size_t ance_encoder_workspace_bytes(const AnceEncoderDesc *desc);
 

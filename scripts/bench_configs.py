@@ -123,6 +123,7 @@ def main():
 def search_config4(torch, dev, steps, n_docs=3213835, nq=32768, k=200):
     """Exact top-200 over the 12.86 M chunk vectors of configuration 4 (rows: LayerNorm-distributed random vectors; all-pad
     chunks -- those past the document's length, lengths as in the encode case above -- are one identical vector)."""
+    from ance_amd import _lib
     from ance_amd.index import FlatIPIndex
     rng = np.random.default_rng(4)
     lens = np.clip(np.rint(rng.lognormal(np.log(1100.0), 0.9, size=n_docs)), 32, 2048).astype(np.int64)
