@@ -120,35 +120,40 @@ __device__ __forceinline__ void gemm256_epilogue(const GemmArgs &G, f32x16 (&acc
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
             epi_sync<WAVE_SYNC>();
+            float bias[2], cs[2] = {0.f, 0.f};  // per-lane row (feature) constants of the two 32-row blocks of this pass
 #pragma unroll
             for (int yy = 0; yy < 2; ++yy) {
-                float bias, cs = 0.f;
                 if constexpr (FOLD) {
-                    bias = smem_f[EPB_OFF + EPB_VEC + wm * 128 + (2 * p + yy) * 32 + i];
-                    cs = smem_f[EPB_OFF + EPB_VEC + 256 + wm * 128 + (2 * p + yy) * 32 + i];
+                    bias[yy] = smem_f[EPB_OFF + EPB_VEC + wm * 128 + (2 * p + yy) * 32 + i];
+                    cs[yy] = smem_f[EPB_OFF + EPB_VEC + 256 + wm * 128 + (2 * p + yy) * 32 + i];
                 } else {
-                    bias = G.bias[mw0 + (2 * p + yy) * 32 + i];
+                    bias[yy] = G.bias[mw0 + (2 * p + yy) * 32 + i];
                 }
+            }
 #pragma unroll
-                for (int x = 0; x < 2; ++x)
+            for (int x = 0; x < 2; ++x)
 #pragma unroll
-                    for (int rq = 0; rq < 4; ++rq) {
+                for (int rq = 0; rq < 4; ++rq) {
+                    // FOLD: tokens are the columns -- (mean, rstd) of 4 consecutive tokens = 32 bytes of LDS, read once per
+                    // pass and column quad; r (acc - mu c) + b = acc r + (b - (mu r) c)
+                    f32x4 r4 = {1.f, 1.f, 1.f, 1.f}, mr4 = {0.f, 0.f, 0.f, 0.f};
+                    if constexpr (FOLD) {
+                        const float *sp = smem_f + EPB_OFF + EPB_STATS + 2 * (wn * 64 + x * 32 + 8 * rq + 4 * g);
+                        const f32x4 s01 = *reinterpret_cast<const f32x4 *>(sp);
+                        const f32x4 s23 = *reinterpret_cast<const f32x4 *>(sp + 4);
+                        r4 = f32x4{s01[1], s01[3], s23[1], s23[3]};
+                        mr4 = f32x4{s01[0] * s01[1], s01[2] * s01[3], s23[0] * s23[1], s23[2] * s23[3]};
+                    }
+#pragma unroll
+                    for (int yy = 0; yy < 2; ++yy) {
                         const f32x16 &a = acc[x][2 * p + yy];
                         f32x4 t = f32x4{a[4 * rq], a[4 * rq + 1], a[4 * rq + 2], a[4 * rq + 3]};
-                        if constexpr (FOLD) {  // tokens are the columns: (mean, rstd) of 4 consecutive tokens = 32 bytes
-                            const float *sp = smem_f + EPB_OFF + EPB_STATS + 2 * (wn * 64 + x * 32 + 8 * rq + 4 * g);
-                            const f32x4 s01 = *reinterpret_cast<const f32x4 *>(sp);
-                            const f32x4 s23 = *reinterpret_cast<const f32x4 *>(sp + 4);
-                            t[0] = (t[0] - s01[0] * cs) * s01[1];
-                            t[1] = (t[1] - s01[2] * cs) * s01[3];
-                            t[2] = (t[2] - s23[0] * cs) * s23[1];
-                            t[3] = (t[3] - s23[2] * cs) * s23[3];
-                        }
+                        if constexpr (FOLD) t = t * r4 + (bias[yy] - mr4 * cs[yy]);
+                        else t = t + bias[yy];
                         *reinterpret_cast<f16x4 *>(slab + (yy * 32 + i) * LS + x * 32 + 8 * rq + 4 * g) =
-                            f16x4{(_Float16)(t[0] + bias), (_Float16)(t[1] + bias), (_Float16)(t[2] + bias),
-                                  (_Float16)(t[3] + bias)};
+                            f16x4{(_Float16)t[0], (_Float16)t[1], (_Float16)t[2], (_Float16)t[3]};
                     }
-            }
+                }
             epi_sync<WAVE_SYNC>();
             if (tok_ok) {
                 _Float16 *obase = G.out16 + (size_t)(mw0 + p * 64) * G.ldc + col;
@@ -279,30 +284,36 @@ __device__ __forceinline__ void gemm256_epilogue(const GemmArgs &G, f32x16 (&acc
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
             epi_sync<WAVE_SYNC>();
+            // per-lane row constants of the two 32-row blocks of this pass (FOLD: r and mu r of the token; tokens are the rows)
+            float rs[2] = {1.f, 1.f}, mrs[2] = {0.f, 0.f};
+            if constexpr (FOLD) {
 #pragma unroll
-            for (int yy = 0; yy < 2; ++yy) {
-                float mu = 0.f, rs = 1.f;
-                if constexpr (FOLD) {  // tokens are the rows: one (mean, rstd) per lane and 32-row block
+                for (int yy = 0; yy < 2; ++yy) {
                     const float *sp = smem_f + EPB_OFF + EPB_STATS + 2 * (wm * 128 + (2 * p + yy) * 32 + i);
-                    mu = sp[0];
-                    rs = sp[1];
+                    rs[yy] = sp[1];
+                    mrs[yy] = sp[0] * sp[1];
                 }
+            }
 #pragma unroll
-                for (int x = 0; x < 2; ++x)
+            for (int x = 0; x < 2; ++x)
 #pragma unroll
-                    for (int rq = 0; rq < 4; ++rq) {
+                for (int rq = 0; rq < 4; ++rq) {
+                    const int nl = x * 32 + 8 * rq + 4 * g;  // local n of element 0
+                    // column constants once per column quad (they come from LDS in the folded epilogues: one read per pass
+                    // and quad instead of one per 32-row block)
+                    f32x4 bias, cs = {0.f, 0.f, 0.f, 0.f};
+                    if constexpr (FOLD) {
+                        bias = *reinterpret_cast<const f32x4 *>(smem_f + EPB_OFF + EPB_VEC + wn * 64 + nl);
+                        cs = *reinterpret_cast<const f32x4 *>(smem_f + EPB_OFF + EPB_VEC + 256 + wn * 64 + nl);
+                    } else {
+                        bias = *reinterpret_cast<const f32x4 *>(G.bias + nw0 + nl);
+                    }
+#pragma unroll
+                    for (int yy = 0; yy < 2; ++yy) {
                         const f32x16 &a = acc[x][2 * p + yy];
-                        const int nl = x * 32 + 8 * rq + 4 * g;  // local n of element 0
-                        f32x4 bias;
                         f32x4 t = f32x4{a[4 * rq], a[4 * rq + 1], a[4 * rq + 2], a[4 * rq + 3]};
-                        if constexpr (FOLD) {
-                            bias = *reinterpret_cast<const f32x4 *>(smem_f + EPB_OFF + EPB_VEC + wn * 64 + nl);
-                            const f32x4 cs = *reinterpret_cast<const f32x4 *>(smem_f + EPB_OFF + EPB_VEC + 256 + wn * 64 + nl);
-                            t = (t - mu * cs) * rs;
-                        } else {
-                            bias = *reinterpret_cast<const f32x4 *>(G.bias + nw0 + nl);
-                        }
-                        t = t + bias;
+                        if constexpr (FOLD) t = t * rs[yy] + (bias - mrs[yy] * cs);  // r (acc - mu c) + b'
+                        else t = t + bias;
                         if constexpr (EPI == EPI_GELU) {
                             t = gelu_erf256(t);
                         } else {
@@ -311,7 +322,7 @@ __device__ __forceinline__ void gemm256_epilogue(const GemmArgs &G, f32x16 (&acc
                         const f16x4 v = f16x4{(_Float16)t[0], (_Float16)t[1], (_Float16)t[2], (_Float16)t[3]};
                         *reinterpret_cast<f16x4 *>(slab + (yy * 32 + i) * LS + nl) = v;
                     }
-            }
+                }
             epi_sync<WAVE_SYNC>();
             // read back: 8 lanes cover one row (64 halves = 128 B), 8 rows per instruction
             const int c8 = l & 7;
