@@ -306,7 +306,15 @@ int launch_gemm_f16(int epi, const GemmArgs &G, hipStream_t st) {
         set_last_error("gemm_f16: M,N must be multiples of 256 and K a multiple of 64, >= 128");
         return ANCE_E_INVALID;
     }
-    return G.debug_mode ? launch256<true>(epi, G, st) : launch256<false>(epi, G, st);
+#ifdef ANCE_MEASURE  // the ablation / timeline builds of the kernel exist in the measurement library only
+    if (G.debug_mode) return launch256<true>(epi, G, st);
+#else
+    if (G.debug_mode) {
+        set_last_error("gemm_f16: ablation and timeline modes need the measurement library (make -C ance_amd/csrc measure)");
+        return ANCE_E_INVALID;
+    }
+#endif
+    return launch256<false>(epi, G, st);
 }
 
 }  // namespace ance

@@ -224,7 +224,8 @@ int ance_encode_ids(AnceEncoder *enc, const int32_t *d_ids, int64_t ld_ids, cons
  * Test / measurement hook: C = A . B^T (+ epilogue) with the encoder's GEMM kernel on caller data.
  *   epi 0: out f16 = acc + bias[n]; 1: out f16 = gelu(acc + bias[n]); 2: out f32 = acc + bias[n] + res32
  *   d_a_f16 [M,K], d_b_f16 [N,K] fp16 row-major; M, N multiples of 256, K a multiple of 64, >= 128.
- *   ablate 0: the product kernel (ping-pong main loop).  Non-zero selects the two-phase loop it
+ *   ablate 0: the product kernel (ping-pong main loop).  Non-zero values are accepted by the MEASUREMENT library only
+ *   (`make -C ance_amd/csrc measure`; the product library returns ANCE_E_INVALID) and select the two-phase loop it
  *   replaced, with measurement ablations by bit (results are then WRONG on purpose): 1 = no global
  *   loads after the first K-tile, 2 = no MFMA, 4 = every block loads tile (0,0); 8 = no ablation
  *   (correct results; the A/B reference for the main loop).  16 + bits: the ping-pong loop with

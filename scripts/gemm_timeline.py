@@ -12,6 +12,8 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+# the timeline build of the kernel exists in the measurement library only (make -C ance_amd/csrc measure)
+os.environ.setdefault("ANCE_AMD_LIB", os.path.join(ROOT, "ance_amd", "libance_amd_measure.so"))
 from ance_amd import _lib  # noqa: E402
 
 
