@@ -178,6 +178,28 @@ def test_many_short_queries_cross_micro_batches():
     _report("short_queries", got[pick], want)
 
 
+@pytest.mark.parametrize("switch", ["ANCE_LN_FOLD", "ANCE_HEAD_MFMA", "ANCE_ATTN_COAL", "ANCE_CLS_TAIL", "ANCE_ENCODER_STREAMS"])
+def test_ab_switches_keep_parity(monkeypatch, switch):
+    """The A/B switches of include/ance_amd.h select the previous form of one piece each (LayerNorm kernels instead of the
+    folded epilogues, block-per-sequence head, per-lane attention I/O, full last layer, one internal stream).  They are what
+    the same-box A/B numbers of DESIGN.md are measured with, so they must stay inside the stated tolerance -- and rows must
+    not depend on the micro-batch split under any of them."""
+    from ance_amd.encoder import ARCH_ROBERTA, Encoder
+    from oracle import encoder_ref, synth
+    monkeypatch.setenv(switch, "1" if switch == "ANCE_ENCODER_STREAMS" else "0")
+    sd = encoder_ref.random_state_dict(seed=15, n_layers=4, ln_jitter=0.1)
+    rng = np.random.default_rng(18)
+    lens = np.array([1, 2, 31, 32, 33, 64, 65, 96, 97, 128, 70, 9, 100, 50, 77, 128, 3, 45, 120, 12], dtype=np.int32)
+    ids = synth.make_records(rng, len(lens), 128, lens.astype(np.int64))
+    with torch.no_grad():
+        want = encoder_ref.rdot_nll_ln_emb(sd, torch.from_numpy(ids), encoder_ref.mask_from_lengths(lens, 128), n_layers=4).numpy()
+    enc = Encoder(sd, ARCH_ROBERTA, "roberta.", True, max_seq_len=128, max_tokens=2048)
+    got = enc.encode_ids(torch.from_numpy(ids).cuda(), torch.from_numpy(lens).cuda(), h_lens=lens)
+    _report("switch_%s" % switch, got.cpu().numpy(), want)
+    enc_small = Encoder(sd, ARCH_ROBERTA, "roberta.", True, max_seq_len=128, max_tokens=512)
+    assert torch.equal(enc_small.encode_ids(torch.from_numpy(ids).cuda(), torch.from_numpy(lens).cuda(), h_lens=lens), got)
+
+
 def test_fp32_mode_against_oracle(monkeypatch):
     """ANCE_ENCODER_PRECISE=1 (csrc/precise32.h): fp32 operands on the fp32-input matrix cores, exact erf GELU, fp32
     softmax -- the reference's arithmetic (model/models.py:149-157).  Against the fp32 oracle only the summation order
