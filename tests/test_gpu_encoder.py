@@ -234,6 +234,29 @@ def test_fp32_mode_against_oracle(monkeypatch):
     assert d5 <= 2e-5, d5
 
 
+def test_fp32_mode_bert_and_maxp_goldens(monkeypatch, golden_dir):
+    """The fp32 mode on the other two model families, against golden vectors of the REFERENCE's own classes
+    (HFBertEncoder raw [CLS] without a head; RobertaDot_CLF_ANN_NLL_MultiChunk with all-pad chunks): 2e-5."""
+    from ance_amd.encoder import ARCH_BERT, ARCH_ROBERTA, AnceModel, Encoder
+    monkeypatch.setenv("ANCE_ENCODER_PRECISE", "1")
+    sd = _weights(_manifest(golden_dir)["encoder"]["bert"], kind="bert", vocab=30522, max_pos=512, head=False, prefixes=("ctx_model.",))
+    g = np.load(os.path.join(golden_dir, "encoder_bert.npz"))
+    enc = Encoder(sd, ARCH_BERT, "ctx_model.", False, max_seq_len=256, max_tokens=4096)
+    ids = torch.from_numpy(g["ids"]).cuda()
+    emb = enc.embed(ids, (ids != 0).long()).cpu().numpy()
+    assert np.abs(emb - g["emb"]).max() <= 2e-5, np.abs(emb - g["emb"]).max()
+    del enc
+    sd = _weights(_manifest(golden_dir)["encoder"]["maxp"])
+    g = np.load(os.path.join(golden_dir, "encoder_maxp.npz"))
+    enc = Encoder(sd, ARCH_ROBERTA, "roberta.", True, max_seq_len=512, max_tokens=8192)
+    model = AnceModel("rdot_nll_multi_chunk", enc, chunks=4)
+    ids = torch.from_numpy(g["ids"]).cuda()
+    mask = (torch.arange(2048)[None, :] < torch.from_numpy(g["lens"])[:, None]).long().cuda()
+    e = model.module.body_emb(input_ids=ids.long(), attention_mask=mask).cpu().numpy()
+    assert np.abs(e - g["emb"]).max() <= 2e-5, np.abs(e - g["emb"]).max()
+    assert np.array_equal(e[4, 1], e[4, 3]) and np.array_equal(e[4, 1], e[3, 2])  # all-pad chunks: one vector
+
+
 def test_missing_extension_is_loud(monkeypatch, tmp_path):
     from ance_amd import _lib
     monkeypatch.setattr(_lib, "_lib", None)
