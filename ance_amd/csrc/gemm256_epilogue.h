@@ -246,12 +246,16 @@ __device__ __forceinline__ void gemm256_epilogue(const GemmArgs &G, f32x16 (&acc
                         f32x4{a[4 * rq], a[4 * rq + 1], a[4 * rq + 2], a[4 * rq + 3]};
                 }
             epi_sync<WAVE_SYNC>();
+            // running pointers (a row step is 4 rows): 64-bit address arithmetic per store was a fifth of this loop
+            const size_t row0 = (size_t)(mw0 + y * 32 + (l >> 4));
+            _Float16 *ph = G.out16 + row0 * G.ldc + nw0 + c4 * 4;
+            _Float16 *pl = G.out_lo + row0 * G.ldc + nw0 + c4 * 4;
+            const size_t rstep = (size_t)4 * G.ldc;
+            f32x4 vv[8];
 #pragma unroll
             for (int it = 0; it < 8; ++it) {
                 const int rr = it * 4 + (l >> 4);
-                const size_t row = (size_t)(mw0 + y * 32 + rr);
-                // acc + bias + LayerNorm(hi + lo) = acc + hi a + (lo a + (bias + beta - mean a)),  a = rstd gamma: two
-                // mixed-precision FMAs per element (v_fma_mix_f32 takes the fp16 halves as they are)
+                // acc + bias + LayerNorm(hi + lo) = acc + hi a + (lo a + (bias + beta - mean a)),  a = rstd gamma
                 f32x4 v = *reinterpret_cast<const f32x4 *>(slab + rr * LS + c4 * 4);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -262,16 +266,43 @@ __device__ __forceinline__ void gemm256_epilogue(const GemmArgs &G, f32x16 (&acc
                 const f16x4 hi = f16x4{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
                 const f16x4 lo = f16x4{(_Float16)(v[0] - (float)hi[0]), (_Float16)(v[1] - (float)hi[1]),
                                        (_Float16)(v[2] - (float)hi[2]), (_Float16)(v[3] - (float)hi[3])};
-                *reinterpret_cast<f16x4 *>(G.out16 + row * G.ldc + nw0 + c4 * 4) = hi;
-                *reinterpret_cast<f16x4 *>(G.out_lo + row * G.ldc + nw0 + c4 * 4) = lo;
-                const float m64 = row16_sum((v[0] + v[1]) + (v[2] + v[3])) * (1.0f / 64.0f);
-                const float d0 = v[0] - m64, d1 = v[1] - m64, d2 = v[2] - m64, d3 = v[3] - m64;
-                const float q64 = row16_sum((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3));
-                if (c4 == 0) {
-                    float *pp = G.part_out + (row * n_parts + slice) * 2;
-                    pp[0] = m64;
-                    pp[1] = q64;
-                }
+                *reinterpret_cast<f16x4 *>(ph + it * rstep) = hi;
+                *reinterpret_cast<f16x4 *>(pl + it * rstep) = lo;
+                vv[it] = v;
+            }
+            // slice statistics of the 8 rows together: eight independent 16-lane reductions interleave (a DPP add right
+            // behind the add that feeds it needs wait states; one row at a time the chain was serial)
+            float s8[8], q8[8];
+#pragma unroll
+            for (int it = 0; it < 8; ++it) s8[it] = (vv[it][0] + vv[it][1]) + (vv[it][2] + vv[it][3]);
+#pragma unroll
+            for (int it = 0; it < 8; ++it) s8[it] += __builtin_amdgcn_update_dpp(0.f, s8[it], 0xB1, 0xF, 0xF, true);
+#pragma unroll
+            for (int it = 0; it < 8; ++it) s8[it] += __builtin_amdgcn_update_dpp(0.f, s8[it], 0x4E, 0xF, 0xF, true);
+#pragma unroll
+            for (int it = 0; it < 8; ++it) s8[it] += __builtin_amdgcn_update_dpp(0.f, s8[it], 0x124, 0xF, 0xF, true);
+#pragma unroll
+            for (int it = 0; it < 8; ++it) s8[it] += __builtin_amdgcn_update_dpp(0.f, s8[it], 0x128, 0xF, 0xF, true);
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const float m64 = s8[it] * (1.0f / 64.0f);
+                s8[it] = m64;
+                const float d0 = vv[it][0] - m64, d1 = vv[it][1] - m64, d2 = vv[it][2] - m64, d3 = vv[it][3] - m64;
+                q8[it] = (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+            }
+#pragma unroll
+            for (int it = 0; it < 8; ++it) q8[it] += __builtin_amdgcn_update_dpp(0.f, q8[it], 0xB1, 0xF, 0xF, true);
+#pragma unroll
+            for (int it = 0; it < 8; ++it) q8[it] += __builtin_amdgcn_update_dpp(0.f, q8[it], 0x4E, 0xF, 0xF, true);
+#pragma unroll
+            for (int it = 0; it < 8; ++it) q8[it] += __builtin_amdgcn_update_dpp(0.f, q8[it], 0x124, 0xF, 0xF, true);
+#pragma unroll
+            for (int it = 0; it < 8; ++it) q8[it] += __builtin_amdgcn_update_dpp(0.f, q8[it], 0x128, 0xF, 0xF, true);
+            if (c4 == 0) {
+                float *pp = G.part_out + (row0 * n_parts + slice) * 2;
+                const size_t pstep = (size_t)4 * n_parts * 2;
+#pragma unroll
+                for (int it = 0; it < 8; ++it) *reinterpret_cast<float2 *>(pp + it * pstep) = make_float2(s8[it], q8[it]);
             }
         }
     } else {
