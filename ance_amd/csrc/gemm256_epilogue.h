@@ -357,11 +357,13 @@ __device__ __forceinline__ void gemm256_epilogue(const GemmArgs &G, f32x16 (&acc
             epi_sync<WAVE_SYNC>();
             // read back: 8 lanes cover one row (64 halves = 128 B), 8 rows per instruction
             const int c8 = l & 7;
+            _Float16 *po = G.out16 + (size_t)(mw0 + p * 64 + (l >> 3)) * G.ldc + nw0 + c8 * 8;  // running pointer: 8 rows per step
+            const size_t ostep = (size_t)8 * G.ldc;
 #pragma unroll
             for (int it = 0; it < 8; ++it) {
                 const int rr = it * 8 + (l >> 3);
                 const f16x8 v = *reinterpret_cast<const f16x8 *>(slab + rr * LS + c8 * 8);
-                *reinterpret_cast<f16x8 *>(G.out16 + (size_t)(mw0 + p * 64 + rr) * G.ldc + nw0 + c8 * 8) = v;
+                *reinterpret_cast<f16x8 *>(po + it * ostep) = v;
             }
         }
     }
