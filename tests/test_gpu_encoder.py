@@ -257,6 +257,38 @@ def test_fp32_mode_bert_and_maxp_goldens(monkeypatch, golden_dir):
     assert np.array_equal(e[4, 1], e[4, 3]) and np.array_equal(e[4, 1], e[3, 2])  # all-pad chunks: one vector
 
 
+@pytest.mark.parametrize("L,n,max_tokens,seed", [(128, 900, 4096, 1), (64, 2000, 2048, 2), (512, 60, 4096, 3), (32, 1500, 512, 4)])
+def test_random_batches_default_against_fp32_mode(monkeypatch, L, n, max_tokens, seed):
+    """Random lengths (uniform 1..L: many one-token sequences, every tile edge), batches that cross many micro-batch
+    boundaries, both kinds of tail (more than 256 [CLS] rows in a micro-batch / fewer): the default mode against the fp32
+    mode of the same library on the same records -- two independent implementations of every kernel (fp16 MFMA + folded
+    LayerNorm + LDS attention vs fp32 MFMA + LayerNorm kernels + vector-unit attention) must agree within the stated
+    tolerance on every row."""
+    from ance_amd.encoder import ARCH_ROBERTA, Encoder
+    from oracle import encoder_ref, synth
+    sd = encoder_ref.random_state_dict(seed=30 + seed, n_layers=3, ln_jitter=0.1)
+    rng = np.random.default_rng(100 + seed)
+    lens = rng.integers(1, L + 1, size=n).astype(np.int32)
+    lens[:8] = [1, 1, L, L, 2, L - 1, 33 % L + 1, 1]
+    ids = synth.make_records(rng, n, L, lens.astype(np.int64))
+    ids_d, lens_d = torch.from_numpy(ids).cuda(), torch.from_numpy(lens).cuda()
+    enc = Encoder(sd, ARCH_ROBERTA, "roberta.", True, max_seq_len=L, max_tokens=max_tokens)
+    a = enc.encode_ids(ids_d, lens_d, h_lens=lens)
+    del enc
+    monkeypatch.setenv("ANCE_ENCODER_PRECISE", "1")
+    enc32 = Encoder(sd, ARCH_ROBERTA, "roberta.", True, max_seq_len=L, max_tokens=max_tokens)
+    b = enc32.encode_ids(ids_d, lens_d, h_lens=lens)
+    assert torch.isfinite(a).all() and torch.isfinite(b).all()
+    d = (a - b).abs().max(dim=1).values
+    assert float(d.max()) <= ABS_TOL, (float(d.max()), int(d.argmax()), int(lens[int(d.argmax())]))
+    # identical inputs -> identical rows, wherever they sit in the batch
+    same = np.flatnonzero((lens == 1))
+    if len(same) > 1:
+        first = ids[same[0], 0]
+        twins = [int(r) for r in same if ids[r, 0] == first]
+        assert all(torch.equal(a[twins[0]], a[r]) for r in twins)
+
+
 def test_missing_extension_is_loud(monkeypatch, tmp_path):
     from ance_amd import _lib
     monkeypatch.setattr(_lib, "_lib", None)
