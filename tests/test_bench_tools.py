@@ -54,3 +54,30 @@ def test_gpus_flag_refuses_to_measure_fewer_devices(tmp_path):
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4"], capture_output=True, text=True, env=env,
                        timeout=300)
     assert r.returncode == 2 and "WORLD_SIZE" in r.stderr
+
+
+def test_roofline_evidence_helpers_quote_only_this_round(tmp_path, monkeypatch):
+    """bench.py reads counters (profiles/pmc_traffic.json) and kernel-trace averages (profiles/rNN_*.csv) into the JSON line:
+    an entry of another round must not be quoted (stale round-1 counters were printed under round-2 kernels),
+    and frac_from_profiles comes from the CSV row of the named kernel."""
+    import json
+    import bench
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    (prof / "pmc_traffic.json").write_text(json.dumps({"encode": {
+        "gemm_ffn1": {"round": bench.CURRENT_ROUND, "hbm_bytes_per_launch": 1.0},
+        "gemm_qk": {"round": "r01", "hbm_bytes_per_launch": 2.0},
+        "gemm_res": {"round": bench.CURRENT_ROUND + " (final)", "hbm_bytes_per_launch": 3.0}}}))
+    (prof / ("%s_rocprofv3_encode_single_stream_kernel_stats.csv" % bench.CURRENT_ROUND)).write_text(
+        '"Name","Calls","TotalDurationNs","AverageNs","Percentage","MinNs","MaxNs","StdDev"\n'
+        '"void ance::(anonymous namespace)::gemm256_f16_desc_kernel<6>(ance::GemmArgs)",10,3000000,300000.0,50,1,2,3\n'
+        '"void ance::(anonymous namespace)::gemm256_f16_desc_kernel<4>(ance::GemmArgs)",20,4000000,200000.0,50,1,2,3\n')
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    assert bench.pmc_traffic("encode", "gemm_ffn1")["hbm_bytes_per_launch"] == 1.0
+    assert bench.pmc_traffic("encode", "gemm_qk") is None                       # another round's counters
+    assert bench.pmc_traffic("encode", "gemm_ffn2")["hbm_bytes_per_launch"] == 3.0  # both RES GEMMs are one kernel
+    assert bench.pmc_traffic("search", "ip_topk_fast") is None
+    name = "%s_rocprofv3_encode_single_stream_kernel_stats.csv" % bench.CURRENT_ROUND
+    assert bench.trace_avg_ns(name, bench.KERNEL_OF["gemm_ffn1"]) == 300000.0
+    assert bench.trace_avg_ns(name, bench.KERNEL_OF["gemm_attn_out"]) == 200000.0
+    assert bench.trace_avg_ns("missing.csv", "x") is None
