@@ -48,7 +48,7 @@ constexpr int H = 768;          // hidden size this build is specialised for
 constexpr int HEAD_OUT = 768;   // embeddingHead output (model/models.py:145)
 constexpr int S_CAP_MAX = 8192; // sequences per micro-batch
 constexpr int FETCH_CHUNK = 262144;
-constexpr int MAX_LANES = 4;     // activation sets / internal streams (default 2; ANCE_ENCODER_STREAMS)
+constexpr int MAX_LANES = 2;     // activation sets / internal streams (3 and 4 lanes measured no gain: DESIGN.md 9)
 
 // ------------------------------------------------------------------------------------ kernels --
 
@@ -1072,24 +1072,9 @@ extern "C" int ance_encoder_create(const AnceEncoderDesc *desc, const void *cons
     e->ev_fork = nullptr;
     if (e->n_lanes > 1) {
         bool ok = hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) == hipSuccess;
-        // ANCE_CU_SPLIT (experiment): every lane's stream owns a disjoint share of the CUs, so that the lanes never wait for
-        // each other's workgroups and the epilogue bursts of one lane's GEMM fall into the main loops of the others.
-        // 1: contiguous bit ranges of the 256-bit CU mask, 2: bit % lanes, 3: 32-bit word % lanes
-        const char *cs = getenv("ANCE_CU_SPLIT");
-        const int split = cs ? atoi(cs) : 0;
-        for (int ln = 0; ln < e->n_lanes && ok; ++ln) {
-            if (split >= 1 && split <= 3) {
-                uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-                for (int b = 0; b < 256; ++b) {
-                    const int owner = split == 1 ? b / (256 / e->n_lanes) : (split == 2 ? b % e->n_lanes : (b / 32) % e->n_lanes);
-                    if (owner == ln) mask[b >> 5] |= 1u << (b & 31);
-                }
-                ok = hipExtStreamCreateWithCUMask(&e->side[ln], 8, mask) == hipSuccess;
-            } else {
-                ok = hipStreamCreateWithFlags(&e->side[ln], hipStreamNonBlocking) == hipSuccess;
-            }
-            ok = ok && hipEventCreateWithFlags(&e->ev_join[ln], hipEventDisableTiming) == hipSuccess;
-        }
+        for (int ln = 0; ln < e->n_lanes && ok; ++ln)
+            ok = hipStreamCreateWithFlags(&e->side[ln], hipStreamNonBlocking) == hipSuccess &&
+                 hipEventCreateWithFlags(&e->ev_join[ln], hipEventDisableTiming) == hipSuccess;
         if (!ok) {
             delete e;
             return check_launch("ance_encoder_create: streams");

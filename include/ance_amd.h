@@ -184,7 +184,7 @@ typedef struct AnceEncoder AnceEncoder;
  * Environment, read when a handle is created (the two size queries read ANCE_ENCODER_PRECISE as well):
  *   ANCE_ENCODER_PRECISE=1   fp32 mode: fp32 operands on the fp32-input matrix cores, exact erf GELU, fp32 softmax -- the
  *                            reference's arithmetic (model/models.py:149-157); max |delta| 1e-5, ~9 x slower
- *   ANCE_ENCODER_STREAMS=n   internal streams / activation sets (1..4, default 2)
+ *   ANCE_ENCODER_STREAMS=n   internal streams / activation sets (1 or 2, default 2)
  *   ANCE_LN_FOLD=0 ANCE_HEAD_MFMA=0 ANCE_CLS_TAIL=0 ANCE_ATTN_COAL=0 ANCE_GEMM_DESC=0   A/B switches back to the previous
  *                            form of one piece each (LayerNorm kernels, per-sequence head, full last layer, per-lane
  *                            attention loads / stores, flat-pointer GEMM staging) */

@@ -22,7 +22,7 @@ def h16(x):
 
 
 def stats_from_slices(v, eps):
-    """(mean, rstd) of the rows of v [T, 768] from per-64-column (mean, M2), as EPI_RESLN + ln_finalize_kernel."""
+    """(mean, rstd) of the rows of v [T, 768] from per-64-column (mean, M2), as EPI_RESLN writes them and every consumer combines them (stats_from_parts)."""
     T, H = v.shape
     s = v.reshape(T, H // 64, 64)
     m_i = s.mean(-1)
