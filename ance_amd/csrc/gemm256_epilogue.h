@@ -98,7 +98,7 @@ __device__ __forceinline__ void epb_stats(const GemmArgs &G, float *smem_f, int 
 
 template <int EPI_, bool WAVE_SYNC = false>
 __device__ __forceinline__ void gemm256_epilogue(const GemmArgs &G, f32x16 (&acc)[2][4], float *smem_f, int m0, int n0,
-                                                 int w, int l) {
+                                                 int w, int l, unsigned long long *pass_stamps = nullptr) {
     _Float16 *smem = reinterpret_cast<_Float16 *>(smem_f);
     const int g = l >> 5, i = l & 31;
     const int wm = w >> 2, wn = w & 3;
@@ -304,6 +304,9 @@ __device__ __forceinline__ void gemm256_epilogue(const GemmArgs &G, f32x16 (&acc
 #pragma unroll
                 for (int it = 0; it < 8; ++it) *reinterpret_cast<float2 *>(pp + it * pstep) = make_float2(s8[it], q8[it]);
             }
+#ifdef ANCE_MEASURE
+            if (pass_stamps && w == 0 && l == 0) pass_stamps[y] = __builtin_amdgcn_s_memrealtime();
+#endif
         }
     } else {
         // fp16 outputs: slab [64 m][64 n] halves, row stride 72 halves (144 B); 2 passes

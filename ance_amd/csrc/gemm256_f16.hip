@@ -138,6 +138,15 @@ __device__ __forceinline__ void two_phase_loop(const GemmArgs &G, f32x16 (&acc)[
 
 // Product kernel, second form (ANCE_GEMM_DESC=0 selects the first one below for A/B): operands through buffer
 // descriptors (PipeSrcDesc), epilogue passes ordered inside the wave instead of by workgroup barriers.
+#ifdef ANCE_MEASURE
+// measurement library: per-workgroup 100 MHz stamps of the folded kernels (ance_debug_gemm_stamps): [block][8] =
+// start, main loop done, statistics ready, epilogue done, and for EPI_RESLN the end of each of its four passes
+__device__ unsigned long long *g_gemm_stamps = nullptr;
+#define GSTAMP(slot) do { if (stamps_ && tid == 0) stamps_[(size_t)blockIdx.x * 8 + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define GSTAMP(slot) do { } while (0)
+#endif
+
 template <int EPI>
 __global__ void __launch_bounds__(G256_THREADS, 2) gemm256_f16_desc_kernel(const GemmArgs G) {
     extern __shared__ __attribute__((aligned(16))) float smem_f[];
@@ -176,10 +185,22 @@ __global__ void __launch_bounds__(G256_THREADS, 2) gemm256_f16_desc_kernel(const
             P.S.voff[2 + h][j] = (uint32_t)(pipe_b_tile_row(h, r) * G.ldb + ch) * 2u;
         }
     constexpr bool EPB = EPI >= EPI_RESLN;  // folded-LayerNorm epilogues: parameter block by LDS-DMA, ahead of the pipeline's own
+#ifdef ANCE_MEASURE
+    unsigned long long *stamps_ = (EPI == EPI_RESLN && G.debug_mode == 64) ? g_gemm_stamps : nullptr;
+#endif
+    GSTAMP(0);
     if constexpr (EPB) epb_issue<EPI>(G, smem_f, m0, n0, w, l);
     P.run(G.K / TK, acc);
+    GSTAMP(1);
     if constexpr (EPB) epb_stats(G, smem_f, tid);
+    GSTAMP(2);
+#ifdef ANCE_MEASURE
+    gemm256_epilogue<EPI, true>(G, acc, smem_f, m0, n0, w, l, stamps_ ? stamps_ + (size_t)blockIdx.x * 8 + 4 : nullptr);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
     gemm256_epilogue<EPI, true>(G, acc, smem_f, m0, n0, w, l);
+#endif
+    GSTAMP(3);
 }
 
 template <int EPI, bool ABLATE>
@@ -256,6 +277,10 @@ __global__ void __launch_bounds__(G256_THREADS, 2) gemm256_f16_kernel(const Gemm
     gemm256_epilogue<EPI>(G, acc, smem_f, m0_, n0_, w, l);
 }
 
+#ifdef ANCE_MEASURE
+unsigned long long *g_gemm_stamps_host = nullptr;
+#endif
+
 template <bool ABLATE>
 int launch256(int epi, const GemmArgs &G, hipStream_t st) {
     const int MT = G.M / TM, NT = G.N / TN;
@@ -291,6 +316,14 @@ int launch256(int epi, const GemmArgs &G, hipStream_t st) {
         attr_done[ai] |= dbit;
     }
     const size_t lds = epi >= EPI_RESLN ? G256_LDS_BYTES + (size_t)EPB_FLOATS * sizeof(float) : G256_LDS_BYTES;
+#ifdef ANCE_MEASURE
+    if (epi == EPI_RESLN && g_gemm_stamps_host) {
+        GemmArgs G2 = G;
+        G2.debug_mode = 64;
+        hipLaunchKernelGGL(k, dim3(blocks), dim3(G256_THREADS), lds, st, G2);
+        return ANCE_OK;
+    }
+#endif
     hipLaunchKernelGGL(k, dim3(blocks), dim3(G256_THREADS), lds, st, G);
     return ANCE_OK;
 }
@@ -318,6 +351,15 @@ int launch_gemm_f16(int epi, const GemmArgs &G, hipStream_t st) {
 }
 
 }  // namespace ance
+
+#ifdef ANCE_MEASURE
+// measurement library only: while d_stamps != NULL the RES GEMMs of the encoder leave uint64[8] per workgroup at d_stamps
+extern "C" void ance_debug_gemm_stamps(void *d_stamps) {
+    ance::g_gemm_stamps_host = reinterpret_cast<unsigned long long *>(d_stamps);
+    unsigned long long *p = ance::g_gemm_stamps_host;
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(ance::g_gemm_stamps), &p, sizeof(p));
+}
+#endif
 
 // Test / measurement hook (include/ance_amd.h): the encoder's GEMM kernel on caller-provided data.
 extern "C" int ance_debug_gemm(int ablate, int epi, const void *d_a_f16, const void *d_b_f16, int M, int N, int K,
