@@ -12,6 +12,7 @@ struct AttnArgs {
     int ld_qk, ld_vt, ld_ctx;
     int n_heads;
     int cls_only;          // 1: only query 0 of every sequence is computed; its row goes to ctx[s] (compact)
+    int coalesced;         // 1 (default): Q rows and output rows through the wave-private LDS slabs; 0: per-lane loads / stores (A/B)
 };
 
 size_t attention_lds_bytes(int max_seq_len, int n_waves);

@@ -273,10 +273,7 @@ size_t attention_lds_bytes(int max_seq_len, int n_waves) {
 // ramp and tail of four launches (112 us).
 int launch_attention(const AttnArgs &A, int n_seq, int max_seq_len, hipStream_t st) {
     if (n_seq <= 0) return ANCE_OK;
-    static const bool coal = [] {  // ANCE_ATTN_COAL=0: per-lane Q loads / output stores (A/B)
-        const char *e = getenv("ANCE_ATTN_COAL");
-        return !(e && e[0] == '0');
-    }();
+    const bool coal = A.coalesced != 0;
     const size_t lds = attention_lds_bytes(max_seq_len, 4);
     if (lds > 160 * 1024) {
         set_last_error("attention: sequence too long for LDS");

@@ -604,6 +604,7 @@ struct AnceEncoder {
     bool ln_fold;   // LayerNorm folded into the GEMMs (file header; ANCE_LN_FOLD=0 disables)
     bool head_mfma; // embeddingHead as one fp32 MFMA GEMM (ANCE_HEAD_MFMA=0: one block per sequence)
     bool precise;   // fp32 path (precise32.h)
+    bool attn_coal; // attention Q / output rows through LDS slabs (ANCE_ATTN_COAL=0: per-lane accesses)
 };
 
 namespace {
@@ -903,7 +904,7 @@ int encode_impl(AnceEncoder *e, const int32_t *base, int64_t ld, const int32_t *
                 if (rc) return rc;
                 AttnArgs A;
                 A.qk = LN.qk16; A.vt = LN.vt16; A.ctx = LN.ctx16; A.desc = LN.desc;
-                A.ld_qk = 2 * H; A.ld_vt = ldvt; A.ld_ctx = H; A.n_heads = D.n_heads; A.cls_only = tail ? 1 : 0;
+                A.ld_qk = 2 * H; A.ld_vt = ldvt; A.ld_ctx = H; A.n_heads = D.n_heads; A.cls_only = tail ? 1 : 0; A.coalesced = e->attn_coal ? 1 : 0;
                 {
                     ProfScope ps(PC_ATTN, st, 0.0);
                     rc = launch_attention(A, S, maxlen, st);
@@ -1060,6 +1061,8 @@ extern "C" int ance_encoder_create(const AnceEncoderDesc *desc, const void *cons
         e->ln_fold = !(lf && lf[0] == '0');
         const char *hm = getenv("ANCE_HEAD_MFMA");
         e->head_mfma = !(hm && hm[0] == '0');
+        const char *ac = getenv("ANCE_ATTN_COAL");
+        e->attn_coal = !(ac && ac[0] == '0');
         e->precise = precise_env();
         if (e->precise) e->ln_fold = false;  // the fp32 path takes the plain biases and LayerNorm parameters
         const char *ns = getenv("ANCE_ENCODER_STREAMS");

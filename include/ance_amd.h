@@ -187,7 +187,8 @@ typedef struct AnceEncoder AnceEncoder;
  *   ANCE_ENCODER_STREAMS=n   internal streams / activation sets (1 or 2, default 2)
  *   ANCE_LN_FOLD=0 ANCE_HEAD_MFMA=0 ANCE_CLS_TAIL=0 ANCE_ATTN_COAL=0 ANCE_GEMM_DESC=0   A/B switches back to the previous
  *                            form of one piece each (LayerNorm kernels, per-sequence head, full last layer, per-lane
- *                            attention loads / stores, flat-pointer GEMM staging) */
+ *                            attention loads / stores, flat-pointer GEMM staging; ANCE_GEMM_DESC is read at the first GEMM
+ *                            launch of the process, the others per handle) */
 size_t ance_encoder_weight_bytes(const AnceEncoderDesc *desc);
 size_t ance_encoder_workspace_bytes(const AnceEncoderDesc *desc);
 
