@@ -281,15 +281,15 @@ int launch_attention(const AttnArgs &A, int n_seq, int max_seq_len, hipStream_t 
     }
     int dev = 0;
     (void)hipGetDevice(&dev);
-    static size_t attr_set[64] = {0};  // the attribute is per device
-    if (dev < 0 || dev >= 64) dev = 0;
-    if (lds > attr_set[dev]) {
+    static size_t attr_set[64] = {0};  // the attribute is per device (ordinals >= 64: set on every call)
+    const bool tracked = dev >= 0 && dev < 64;
+    if (!tracked || lds > __atomic_load_n(&attr_set[dev], __ATOMIC_ACQUIRE)) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(attention_kernel<true, 4>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
             hipFuncSetAttribute(reinterpret_cast<const void *>(attention_kernel<false, 4>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return check_launch("attention attr");
-        attr_set[dev] = lds;
+        if (tracked) __atomic_store_n(&attr_set[dev], lds, __ATOMIC_RELEASE);
     }
     if (coal) hipLaunchKernelGGL((attention_kernel<true, 4>), dim3((unsigned)n_seq * A.n_heads), dim3(256), lds, st, A);
     else hipLaunchKernelGGL((attention_kernel<false, 4>), dim3((unsigned)n_seq * A.n_heads), dim3(256), lds, st, A);

@@ -58,16 +58,22 @@ __device__ inline int lane_id() { return (int)(threadIdx.x & 63); }
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-// hipFuncSetAttribute is per device: one bit per device ordinal (ordinals above 62: set every time).  Returns true when
-// the caller has to set its attributes for the current device.
-inline bool attr_needed(unsigned long long *done) {
+// hipFuncSetAttribute is per device: one bit per device ordinal in a mask that is read and updated atomically (two host
+// threads may drive two GPUs).  attr_needed: the caller has to set its attributes for the current device; attr_mark: they are
+// set -- called only AFTER hipFuncSetAttribute has succeeded, so a failed attempt is retried by the next call.  Ordinals above
+// 62 have no bit: their attributes are set on every call.
+inline int attr_device_bit() {
     int dev = 0;
     (void)hipGetDevice(&dev);
-    if (dev < 0 || dev >= 63) return true;
-    const unsigned long long bit = 1ull << dev;
-    if (*done & bit) return false;
-    *done |= bit;
-    return true;
+    return (dev < 0 || dev >= 63) ? -1 : dev;
+}
+inline bool attr_needed(unsigned long long *done) {
+    const int bit = attr_device_bit();
+    return bit < 0 || !(__atomic_load_n(done, __ATOMIC_ACQUIRE) & (1ull << bit));
+}
+inline void attr_mark(unsigned long long *done) {
+    const int bit = attr_device_bit();
+    if (bit >= 0) (void)__atomic_fetch_or(done, 1ull << bit, __ATOMIC_RELEASE);
 }
 
 }  // namespace ance

@@ -32,6 +32,12 @@
 //   * the consumers of the fp32 value (next RES epilogue, [CLS] gather, head) recompute LN(hi + lo) from the pair.
 // Rounding points that move: the token operand is fp16(v) instead of fp16(LN(v)) -- the same relative rounding of every
 // element, taken before the mean is removed -- and gamma (.) W is rounded once instead of W.  Measured parity: DESIGN.md 4.
+//
+// SPLIT mode (ANCE_ENCODER_SPLIT=1; round 4): an fp32-GRADE result at a third of the fp16 MFMA rate instead of the sixteenth the
+// fp32-input matrix cores run at (precise32.h).  Every GEMM operand is an fp16 pair  v = hi + lo' 2^-11  (rows [hi | lo']),
+// a product is three fp16 MFMA passes on the pipeline of the default mode (gemm256_f16.hip: gemm256_split_kernel), the
+// LayerNorm fold, the fp32 softmax (precise32.h attention, fp32 Q | K | V from the QKV epilogue), the exact-erf GELU and the
+// fp32 head are the reference's arithmetic.  Stated tolerance 2e-5 (tests/test_split_model.py: 3.3e-6 on the CPU model).
 #include <stdlib.h>
 #include <string.h>
 #include <vector>
@@ -294,8 +300,8 @@ __global__ void __launch_bounds__(256) gather_cls_kernel(const float *pre, const
     }
 }
 
-__global__ void __launch_bounds__(256) head_kernel(const float *pre, const _Float16 *hi, const _Float16 *lo, const float *stats,
-                                                   const float *part, float eps, const float *lng, const float *lnb,
+__global__ void __launch_bounds__(256) head_kernel(const float *pre, const _Float16 *hi, const _Float16 *lo, int ldp, float lo_scale,
+                                                   const float *stats, const float *part, float eps, const float *lng, const float *lnb,
                                                    const int *seq_off, int compact, const float *W, const float *b,
                                                    const float *gamma, const float *beta, int has_head, float *out) {
     __shared__ float cls[H];
@@ -307,7 +313,7 @@ __global__ void __launch_bounds__(256) head_kernel(const float *pre, const _Floa
     if (part) stats_from_parts(part + row * 24, eps, &mean_h, &rstd_h);
     else { mean_h = stats[2 * row]; rstd_h = stats[2 * row + 1]; }
     float *dst = out + (size_t)s * HEAD_OUT;
-    auto src = [&](int j) { return hi ? (float)hi[row * H + j] + (float)lo[row * H + j] : pre[row * H + j]; };
+    auto src = [&](int j) { return hi ? (float)hi[row * ldp + j] + (float)lo[row * ldp + j] * lo_scale : pre[row * H + j]; };
     if (!has_head) {
         for (int j = tid; j < H; j += 256) dst[j] = (src(j) - mean_h) * rstd_h * lng[j] + lnb[j];
         return;
@@ -355,9 +361,10 @@ __device__ __forceinline__ void split_store(const f32x4 v, _Float16 *hi, _Float1
     reinterpret_cast<f16x4 *>(hi)[c4] = h;
     reinterpret_cast<f16x4 *>(lo)[c4] = r;
 }
-__device__ __forceinline__ f32x4 pair_load(const _Float16 *hi, const _Float16 *lo, int c4) {
+__device__ __forceinline__ f32x4 pair_load(const _Float16 *hi, const _Float16 *lo, int c4, float lo_scale = 1.0f) {
     const f16x4 h = reinterpret_cast<const f16x4 *>(hi)[c4], r = reinterpret_cast<const f16x4 *>(lo)[c4];
-    return f32x4{(float)h[0] + (float)r[0], (float)h[1] + (float)r[1], (float)h[2] + (float)r[2], (float)h[3] + (float)r[3]};
+    return f32x4{(float)h[0] + (float)r[0] * lo_scale, (float)h[1] + (float)r[1] * lo_scale, (float)h[2] + (float)r[2] * lo_scale,
+                 (float)h[3] + (float)r[3] * lo_scale};
 }
 
 // embeddings -> (hi, lo) pair of the pre-LayerNorm row + the (mean, M2) of its twelve 64-column slices (the format the
@@ -447,6 +454,102 @@ __global__ void __launch_bounds__(256) fold_weight_kernel(const float *W, const 
     }
 }
 
+// ---- split mode ---------------------------------------------------------------------------------
+constexpr float SPLIT_SCALE_H = 2048.0f, SPLIT_INV_H = 1.0f / 2048.0f;
+constexpr int HP = 2 * H;  // halves per pair row of a 768-wide stream: [hi (768) | lo' (768)]
+
+__device__ __forceinline__ void split_store_scaled(const f32x4 v, _Float16 *row, int width, int c4) {
+    const f16x4 h = f16x4{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+    const f16x4 r = f16x4{(_Float16)((v[0] - (float)h[0]) * SPLIT_SCALE_H), (_Float16)((v[1] - (float)h[1]) * SPLIT_SCALE_H),
+                          (_Float16)((v[2] - (float)h[2]) * SPLIT_SCALE_H), (_Float16)((v[3] - (float)h[3]) * SPLIT_SCALE_H)};
+    reinterpret_cast<f16x4 *>(row)[c4] = h;
+    reinterpret_cast<f16x4 *>(row + width)[c4] = r;
+}
+
+// embeddings -> pair rows of the pre-LayerNorm stream + the slice statistics (format of EPI_S_RESLN); one wave per token
+__global__ void __launch_bounds__(256) embed_split_kernel(const int *tok_id, const int *tok_pos, int Tpad, const float *word,
+                                                          const float *pos, const float *type0, int vocab, int max_pos,
+                                                          _Float16 *xp, float *part) {
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int l = threadIdx.x & 63;
+    if (t >= Tpad) return;
+    int id = tok_id[t], p = tok_pos[t];
+    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+    p = p < 0 ? 0 : (p >= max_pos ? max_pos - 1 : p);
+    const f32x4 *w4 = reinterpret_cast<const f32x4 *>(word + (size_t)id * H);
+    const f32x4 *p4 = reinterpret_cast<const f32x4 *>(pos + (size_t)p * H);
+    const f32x4 *t4 = reinterpret_cast<const f32x4 *>(type0);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int c4 = k * 64 + l;
+        const f32x4 v = (w4[c4] + t4[c4]) + p4[c4];  // same association as the reference: (word + type) + pos
+        split_store_scaled(v, xp + (size_t)t * HP, H, c4);
+        const float m64 = row16_sum((v[0] + v[1]) + (v[2] + v[3])) * (1.0f / 64.0f);
+        const float d0 = v[0] - m64, d1 = v[1] - m64, d2 = v[2] - m64, d3 = v[3] - m64;
+        const float q64 = row16_sum((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3));
+        if ((l & 15) == 0) {
+            float *pp = part + ((size_t)t * 12 + 4 * k + (l >> 4)) * 2;
+            pp[0] = m64;
+            pp[1] = q64;
+        }
+    }
+}
+
+// weight load for the split GEMM: row n of W [N, K] -> pair row [hi (K) | lo' (K)] of  g (.) W  (g = the LayerNorm weight
+// folded in, or null), csum[n] = sum_k (hi + lo' 2^-11) (what the MFMA passes actually multiply), bout[n] = b[n] + sum_k
+// beta[k] W[n][k].  One wave per row.
+__global__ void __launch_bounds__(256) split_weight_kernel(const float *W, const float *b, const float *gamma, const float *beta,
+                                                           int N, int K, _Float16 *Wp, float *csum, float *bout) {
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int l = threadIdx.x & 63;
+    if (n >= N) return;
+    const f32x4 *w4 = reinterpret_cast<const f32x4 *>(W + (size_t)n * K);
+    _Float16 *row = Wp + (size_t)n * 2 * K;
+    float cs = 0.f, bs = 0.f;
+    for (int c4 = l; c4 < K / 4; c4 += 64) {
+        f32x4 w = w4[c4];
+        if (gamma) {
+            const f32x4 g = reinterpret_cast<const f32x4 *>(gamma)[c4], be = reinterpret_cast<const f32x4 *>(beta)[c4];
+            bs += (be[0] * w[0] + be[1] * w[1]) + (be[2] * w[2] + be[3] * w[3]);
+            w = w * g;
+        }
+        split_store_scaled(w, row, K, c4);
+        const f16x4 h = reinterpret_cast<const f16x4 *>(row)[c4], r = reinterpret_cast<const f16x4 *>(row + K)[c4];
+        cs += (((float)h[0] + (float)r[0] * SPLIT_INV_H) + ((float)h[1] + (float)r[1] * SPLIT_INV_H)) +
+              (((float)h[2] + (float)r[2] * SPLIT_INV_H) + ((float)h[3] + (float)r[3] * SPLIT_INV_H));
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        cs += __shfl_xor(cs, off);
+        bs += __shfl_xor(bs, off);
+    }
+    if (l == 0) {
+        if (csum) csum[n] = cs;
+        if (bout) bout[n] = b[n] + bs;
+    }
+}
+
+// last layer, CLS-only tail in split mode: compact pair rows + slice partials of the [CLS] tokens; rows S..S_pad zeroed
+__global__ void __launch_bounds__(256) gather_cls_split_kernel(const _Float16 *xp, const float *part, const int *seq_off, int S,
+                                                               int S_pad, _Float16 *cxp, float *cpart) {
+    const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int l = threadIdx.x & 63;
+    if (s >= S_pad) return;
+    f16x8 *d = reinterpret_cast<f16x8 *>(cxp + (size_t)s * HP);
+    if (s < S) {
+        const size_t row = (size_t)seq_off[s];
+        const f16x8 *sp = reinterpret_cast<const f16x8 *>(xp + row * HP);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) d[k * 64 + l] = sp[k * 64 + l];
+        if (l < 24) cpart[(size_t)s * 24 + l] = part[row * 24 + l];
+    } else {
+        const f16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int k = 0; k < 3; ++k) d[k * 64 + l] = z;
+        if (l < 24) cpart[(size_t)s * 24 + l] = (l & 1) ? 64.0f : 0.f;  // mean 0, variance 1: a finite rstd
+    }
+}
+
 // ---- embeddingHead as one fp32 MFMA GEMM over the [CLS] rows (model/models.py:145-152) ----------
 // z[s][n] = sum_k LN(cls_s)[k] W[n][k] + b[n]; 32 sequences x 128 features per workgroup, one 32 x 32 tile per wave
 // (v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulation in k order).  The 32 normalised [CLS] rows are staged
@@ -455,8 +558,8 @@ __global__ void __launch_bounds__(256) fold_weight_kernel(const float *W, const 
 constexpr int HEAD_LDA = H + 4;  // floats; 16 lanes x stride 4 banks: conflict-free ds_read_b128
 constexpr size_t HEAD_LDS_BYTES = (size_t)32 * HEAD_LDA * sizeof(float);
 
-__global__ void __launch_bounds__(256) head_gemm_kernel(const float *pre32, const _Float16 *hi, const _Float16 *lo,
-                                                        const float *stats, const float *part, float eps, const float *lng,
+__global__ void __launch_bounds__(256) head_gemm_kernel(const float *pre32, const _Float16 *hi, const _Float16 *lo, int ldp,
+                                                        float lo_scale, const float *stats, const float *part, float eps, const float *lng,
                                                         const float *lnb, const int *seq_off, int compact, int S, const float *W,
                                                         const float *b, float *out) {
     extern __shared__ __attribute__((aligned(16))) float cls[];
@@ -474,7 +577,7 @@ __global__ void __launch_bounds__(256) head_gemm_kernel(const float *pre32, cons
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
                 const int c4 = k * 64 + l;
-                const f32x4 x = hi ? pair_load(hi + row * H, lo + row * H, c4)
+                const f32x4 x = hi ? pair_load(hi + row * ldp, lo + row * ldp, c4, lo_scale)
                                    : reinterpret_cast<const f32x4 *>(pre32 + row * H)[c4];
                 dst[c4] = ln_apply4(x, mean, rstd, reinterpret_cast<const f32x4 *>(lng)[c4],
                                     reinterpret_cast<const f32x4 *>(lnb)[c4]);
@@ -550,8 +653,17 @@ bool precise_env() {
     return p && p[0] == '1';
 }
 
+// ANCE_ENCODER_SPLIT=1: handles created while it is set run the split (fp32-grade) path; like the fp32 switch it changes the
+// arena and workspace sizes, so the size queries read it too.  ANCE_ENCODER_PRECISE wins when both are set.
+bool split_env() {
+    const char *p = getenv("ANCE_ENCODER_SPLIT");
+    return p && p[0] == '1' && !precise_env();
+}
+
 struct LayerW {
     _Float16 *wqk, *wv, *wo, *w1, *w2;
+    _Float16 *wqkv_s, *wo_s, *w1_s, *w2_s;  // split path: pair rows [hi (K) | lo' (K)]
+    float *bqkv_s, *cqkv_s, *b1_s, *c1_s;   // split path: folded biases and row sums
     float *bqk, *bv, *bo, *b1, *b2, *ln1w, *ln1b, *ln2w, *ln2b;
     float *cqk, *cv, *c1;  // folded LayerNorm: per-feature sums of the folded fp16 weight rows
     float *wqkv32, *bqkv32, *wo32, *w132, *w232;  // fp32 path only
@@ -604,6 +716,8 @@ struct AnceEncoder {
     bool ln_fold;   // LayerNorm folded into the GEMMs (file header; ANCE_LN_FOLD=0 disables)
     bool head_mfma; // embeddingHead as one fp32 MFMA GEMM (ANCE_HEAD_MFMA=0: one block per sequence)
     bool precise;   // fp32 path (precise32.h)
+    bool split;     // split (fp32-grade) path
+    bool n_split;   // FFN1 with the N-split tile order (ANCE_GEMM_NSPLIT=0 disables)
     bool attn_coal; // attention Q / output rows through LDS slabs (ANCE_ATTN_COAL=0: per-lane accesses)
 };
 
@@ -642,6 +756,18 @@ void layout_weights(const AnceEncoderDesc *d, Arena &a, AnceEncoder *e) {
         w.cqk = a.take<float>(2 * H);
         w.cv = a.take<float>(H);
         w.c1 = a.take<float>(I);
+        w.wqkv_s = w.wo_s = w.w1_s = w.w2_s = nullptr;
+        w.bqkv_s = w.cqkv_s = w.b1_s = w.c1_s = nullptr;
+        if (split_env()) {
+            w.wqkv_s = a.take<_Float16>((size_t)3 * H * HP);
+            w.bqkv_s = a.take<float>(3 * H);
+            w.cqkv_s = a.take<float>(3 * H);
+            w.wo_s = a.take<_Float16>((size_t)H * HP);
+            w.w1_s = a.take<_Float16>(I * HP);
+            w.b1_s = a.take<float>(I);
+            w.c1_s = a.take<float>(I);
+            w.w2_s = a.take<_Float16>((size_t)H * 2 * I);
+        }
         w.wqkv32 = w.bqkv32 = w.wo32 = w.w132 = w.w232 = nullptr;
         if (precise_env()) {
             w.wqkv32 = a.take<float>((size_t)3 * H * H);
@@ -688,6 +814,10 @@ void layout_workspace(const AnceEncoderDesc *d, Arena &a, AnceEncoder *e) {
         if (precise_env()) {
             L.x32 = a.take<float>((size_t)tcap * H);
             L.xa32 = a.take<float>((size_t)tcap * H);
+        }
+        if (precise_env() || split_env()) {
+            // split mode: qkv32 = fp32 Q | K | V; ctx32 / ffn32 hold the PAIR rows of the attention output / FFN activation
+            // (an fp16 pair row is as many bytes as the fp32 row)
             L.qkv32 = a.take<float>((size_t)tcap * 3 * H);
             L.ctx32 = a.take<float>((size_t)tcap * H);
             L.ffn32 = a.take<float>((size_t)tcap * d->intermediate);
@@ -845,13 +975,108 @@ int encode_impl(AnceEncoder *e, const int32_t *base, int64_t ld, const int32_t *
                     float *dst = d_out + (size_t)(r0 * n_chunks + gs) * HEAD_OUT;
                     if (D.has_head) {
                         hipLaunchKernelGGL(head_gemm_kernel, dim3((S + 31) / 32, HEAD_OUT / 128), dim3(256), HEAD_LDS_BYTES, st, LN.preB,
-                                           (const _Float16 *)nullptr, (const _Float16 *)nullptr, LN.statsB, (const float *)nullptr,
+                                           (const _Float16 *)nullptr, (const _Float16 *)nullptr, H, 1.0f, LN.statsB, (const float *)nullptr,
                                            D.ln_eps, WL.ln2w, WL.ln2b, LN.seq_off, 0, S, e->head_w, e->head_b, dst);
                         hipLaunchKernelGGL(head_ln_kernel, dim3((S + 3) / 4), dim3(256), 0, st, dst, S, e->norm_w, e->norm_b);
                     } else {
                         hipLaunchKernelGGL(head_kernel, dim3(S), dim3(256), 0, st, LN.preB, (const _Float16 *)nullptr,
-                                           (const _Float16 *)nullptr, LN.statsB, (const float *)nullptr, D.ln_eps, WL.ln2w, WL.ln2b,
+                                           (const _Float16 *)nullptr, H, 1.0f, LN.statsB, (const float *)nullptr, D.ln_eps, WL.ln2w, WL.ln2b,
                                            LN.seq_off, 0, e->head_w, e->head_b, e->norm_w, e->norm_b, 0, dst);
+                    }
+                }
+                gs = g;
+                continue;
+            }
+            if (e->split) {
+                // ---- split (fp32-grade) path: the default mode's schedule with pair operands and the fp32 attention ----
+                _Float16 *const xa = reinterpret_cast<_Float16 *>(LN.preA), *const xb = reinterpret_cast<_Float16 *>(LN.preB);
+                _Float16 *const ctxp = reinterpret_cast<_Float16 *>(LN.ctx32), *const ffnp = reinterpret_cast<_Float16 *>(LN.ffn32);
+                {
+                    ProfScope pe(PC_EMBED, st);
+                    hipLaunchKernelGGL(embed_split_kernel, dim3(Tpad / 4), dim3(256), 0, st, LN.tok_id, LN.tok_pos, Tpad, e->word,
+                                       e->pos, e->type0, D.vocab_size, D.max_position, xb, LN.partB);
+                }
+                const bool cls_tail = e->cls_tail;
+                const int S_pad = (int)align_up((size_t)S, 256);
+                int rc = ANCE_OK;
+                for (int li = 0; li < D.n_layers && !rc; ++li) {
+                    const LayerW &W = e->layers[li];
+                    const bool tail = cls_tail && li == D.n_layers - 1;
+                    const int Mrows = tail ? S_pad : Tpad;
+                    const double Mwork = tail ? (double)S : (double)T;
+                    GemmArgs G;
+                    memset(&G, 0, sizeof(G));
+                    // Q | K | V projection -> fp32 (the LayerNorm that produces this layer's input is folded in)
+                    G.A = xb; G.lda = HP; G.B = W.wqkv_s; G.ldb = HP; G.M = Tpad; G.N = 3 * H; G.K = H;
+                    G.bias = W.bqkv_s; G.csum = W.cqkv_s; G.part_in = LN.partB; G.ln_eps = D.ln_eps;
+                    G.out32 = LN.qkv32; G.ldc = 3 * H;
+                    {
+                        ProfScope ps(PC_GEMM_QK, st, 2.0 * T * (3.0 * H) * H);
+                        rc = launch_gemm_f16(EPI_S_QKV, G, st);
+                    }
+                    if (rc) break;
+                    {
+                        ProfScope ps(PC_ATTN, st);
+                        if (tail && S_pad > S)  // rows S..S_pad of the compact attention output feed the GEMM tile: keep them finite
+                            (void)hipMemsetAsync(ctxp + (size_t)S * HP, 0, (size_t)(S_pad - S) * HP * sizeof(_Float16), st);
+                        rc = launch_attention32(LN.qkv32, nullptr, LN.seq_off, S, D.n_heads, st, ctxp, tail ? 1 : 0);
+                    }
+                    if (rc) break;
+                    // attention.output.dense + residual LayerNorm(x_b), x_b = the previous layer's output (or the embeddings)
+                    memset(&G, 0, sizeof(G));
+                    G.res_gamma = li == 0 ? e->eln_w : e->layers[li - 1].ln2w;
+                    G.res_beta = li == 0 ? e->eln_b : e->layers[li - 1].ln2b;
+                    G.res_hi = xb; G.ldr = HP; G.part_in = LN.partB; G.ln_eps = D.ln_eps;
+                    if (tail) {  // compact pair rows + partials of the [CLS] tokens, parked in the (currently dead) FFN buffer
+                        float *cpt = reinterpret_cast<float *>(ffnp + (size_t)S_pad * HP);
+                        ProfScope ps(PC_LN, st);
+                        hipLaunchKernelGGL(gather_cls_split_kernel, dim3(S_pad / 4), dim3(256), 0, st, xb, LN.partB, LN.seq_off, S, S_pad,
+                                           ffnp, cpt);
+                        G.res_hi = ffnp; G.part_in = cpt;
+                    }
+                    G.A = ctxp; G.lda = HP; G.B = W.wo_s; G.ldb = HP; G.M = Mrows; G.N = H; G.K = H;
+                    G.bias = W.bo; G.out16 = xa; G.ldc = HP; G.part_out = LN.partA;
+                    {
+                        ProfScope ps(PC_GEMM_OUT, st, 2.0 * Mwork * (double)H * H);
+                        rc = launch_gemm_f16(EPI_S_RESLN, G, st);
+                    }
+                    if (rc) break;
+                    // intermediate.dense + exact GELU (attention.output.LayerNorm folded in)
+                    memset(&G, 0, sizeof(G));
+                    G.A = xa; G.lda = HP; G.B = W.w1_s; G.ldb = HP; G.M = Mrows; G.N = I; G.K = H;
+                    G.bias = W.b1_s; G.csum = W.c1_s; G.part_in = LN.partA; G.ln_eps = D.ln_eps;
+                    G.out16 = ffnp; G.ldc = 2 * I; G.n_split = (e->n_split && (I / 256) % 2 == 0) ? 2 : 0;
+                    {
+                        ProfScope ps(PC_GEMM_FFN1, st, 2.0 * Mwork * (double)I * H);
+                        rc = launch_gemm_f16(EPI_S_GELU, G, st);
+                    }
+                    if (rc) break;
+                    // output.dense + residual LayerNorm(x_a)
+                    memset(&G, 0, sizeof(G));
+                    G.A = ffnp; G.lda = 2 * I; G.B = W.w2_s; G.ldb = 2 * I; G.M = Mrows; G.N = H; G.K = I;
+                    G.bias = W.b2; G.res_gamma = W.ln1w; G.res_beta = W.ln1b; G.res_hi = xa; G.ldr = HP;
+                    G.part_in = LN.partA; G.ln_eps = D.ln_eps; G.out16 = xb; G.ldc = HP; G.part_out = LN.partB;
+                    {
+                        ProfScope ps(PC_GEMM_FFN2, st, 2.0 * Mwork * (double)I * H);
+                        rc = launch_gemm_f16(EPI_S_RESLN, G, st);
+                    }
+                }
+                if (rc) return rc;
+                {
+                    ProfScope ps(PC_HEAD, st);
+                    const LayerW &WL = e->layers[D.n_layers - 1];
+                    float *dst = d_out + (size_t)(r0 * n_chunks + gs) * HEAD_OUT;
+                    if (D.has_head) {
+                        hipLaunchKernelGGL(head_gemm_kernel, dim3((S + 31) / 32, HEAD_OUT / 128), dim3(256), HEAD_LDS_BYTES, st,
+                                           (const float *)nullptr, (const _Float16 *)xb, (const _Float16 *)(xb + H), HP, SPLIT_INV_H,
+                                           (const float *)nullptr, (const float *)LN.partB, D.ln_eps, WL.ln2w, WL.ln2b, LN.seq_off,
+                                           cls_tail ? 1 : 0, S, e->head_w, e->head_b, dst);
+                        hipLaunchKernelGGL(head_ln_kernel, dim3((S + 3) / 4), dim3(256), 0, st, dst, S, e->norm_w, e->norm_b);
+                    } else {
+                        hipLaunchKernelGGL(head_kernel, dim3(S), dim3(256), 0, st, (const float *)nullptr, (const _Float16 *)xb,
+                                           (const _Float16 *)(xb + H), HP, SPLIT_INV_H, (const float *)nullptr, (const float *)LN.partB,
+                                           D.ln_eps, WL.ln2w, WL.ln2b, LN.seq_off, cls_tail ? 1 : 0, e->head_w, e->head_b, e->norm_w,
+                                           e->norm_b, 0, dst);
                     }
                 }
                 gs = g;
@@ -885,7 +1110,7 @@ int encode_impl(AnceEncoder *e, const int32_t *base, int64_t ld, const int32_t *
                 G.A = fold ? xb_hi : LN.h16; G.lda = H; G.B = W.wqk; G.ldb = H; G.M = Tpad; G.N = 2 * H; G.K = H;
                 G.bias = W.bqk; G.out16 = LN.qk16; G.ldc = 2 * H; G.scale_cols = H;
                 G.scale = 0.125f * 1.44269504088896340736f;  // 1/sqrt(64) and log2(e): the softmax runs on exp2
-                G.part_in = LN.partB; G.ln_eps = D.ln_eps; G.csum = W.cqk;
+                G.part_in = LN.partB; G.ln_eps = D.ln_eps; G.csum = W.cqk; G.tok_lo = fold ? xb_lo : nullptr;
                 int rc;
                 {
                     ProfScope ps(PC_GEMM_QK, st, 2.0 * T * (2.0 * H) * H);
@@ -896,7 +1121,7 @@ int encode_impl(AnceEncoder *e, const int32_t *base, int64_t ld, const int32_t *
                 memset(&G, 0, sizeof(G));
                 G.A = W.wv; G.lda = H; G.B = fold ? xb_hi : LN.h16; G.ldb = H; G.M = H; G.N = Tpad; G.K = H;
                 G.bias = W.bv; G.out16 = LN.vt16; G.ldc = ldvt; G.col_map = LN.tok_vtcol; G.n_valid = T;
-                G.part_in = LN.partB; G.ln_eps = D.ln_eps; G.csum = W.cv;
+                G.part_in = LN.partB; G.ln_eps = D.ln_eps; G.csum = W.cv; G.tok_lo = fold ? xb_lo : nullptr;
                 {
                     ProfScope ps(PC_GEMM_VT, st, 2.0 * T * (double)H * H);
                     rc = launch_gemm_f16(fold ? EPI_VT_F : EPI_VT, G, st);
@@ -954,7 +1179,8 @@ int encode_impl(AnceEncoder *e, const int32_t *base, int64_t ld, const int32_t *
                 memset(&G, 0, sizeof(G));
                 G.A = fold ? xa_hi : LN.h16; G.lda = H; G.B = W.w1; G.ldb = H; G.M = Mrows; G.N = I; G.K = H;
                 G.bias = W.b1; G.out16 = LN.ffn16; G.ldc = I;
-                G.part_in = LN.partA; G.ln_eps = D.ln_eps; G.csum = W.c1;
+                G.part_in = LN.partA; G.ln_eps = D.ln_eps; G.csum = W.c1; G.tok_lo = fold ? xa_lo : nullptr;
+                G.n_split = (fold && e->n_split && (I / 256) % 2 == 0) ? 2 : 0;
                 {
                     ProfScope ps(PC_GEMM_FFN1, st, 2.0 * Mwork * (double)I * H);
                     rc = launch_gemm_f16(fold ? EPI_GELU_F : EPI_GELU, G, st);
@@ -989,11 +1215,11 @@ int encode_impl(AnceEncoder *e, const int32_t *base, int64_t ld, const int32_t *
                 const _Float16 *hh = fold ? xb_hi : nullptr, *hl = fold ? xb_lo : nullptr;
                 if (D.has_head && e->head_mfma) {
                     hipLaunchKernelGGL(head_gemm_kernel, dim3((S + 31) / 32, HEAD_OUT / 128), dim3(256), HEAD_LDS_BYTES, st, LN.preB, hh,
-                                       hl, LN.statsB, fold ? LN.partB : (const float *)nullptr, D.ln_eps, WL.ln2w, WL.ln2b, LN.seq_off,
+                                       hl, H, 1.0f, LN.statsB, fold ? LN.partB : (const float *)nullptr, D.ln_eps, WL.ln2w, WL.ln2b, LN.seq_off,
                                        cls_tail ? 1 : 0, S, e->head_w, e->head_b, dst);
                     hipLaunchKernelGGL(head_ln_kernel, dim3((S + 3) / 4), dim3(256), 0, st, dst, S, e->norm_w, e->norm_b);
                 } else {
-                    hipLaunchKernelGGL(head_kernel, dim3(S), dim3(256), 0, st, LN.preB, hh, hl, LN.statsB,
+                    hipLaunchKernelGGL(head_kernel, dim3(S), dim3(256), 0, st, LN.preB, hh, hl, H, 1.0f, LN.statsB,
                                        fold ? LN.partB : (const float *)nullptr, D.ln_eps, WL.ln2w, WL.ln2b, LN.seq_off,
                                        cls_tail ? 1 : 0, e->head_w, e->head_b, e->norm_w, e->norm_b, D.has_head, dst);
                 }
@@ -1064,7 +1290,10 @@ extern "C" int ance_encoder_create(const AnceEncoderDesc *desc, const void *cons
         const char *ac = getenv("ANCE_ATTN_COAL");
         e->attn_coal = !(ac && ac[0] == '0');
         e->precise = precise_env();
-        if (e->precise) e->ln_fold = false;  // the fp32 path takes the plain biases and LayerNorm parameters
+        e->split = split_env();
+        if (e->precise || e->split) e->ln_fold = false;  // these paths take the plain biases and LayerNorm parameters
+        const char *nsp = getenv("ANCE_GEMM_NSPLIT");
+        e->n_split = !(nsp && nsp[0] == '0');
         const char *ns = getenv("ANCE_ENCODER_STREAMS");
         e->n_lanes = (ns && ns[0] >= '1' && ns[0] <= '0' + MAX_LANES) ? ns[0] - '0' : 2;
     }
@@ -1132,6 +1361,21 @@ extern "C" int ance_encoder_create(const AnceEncoderDesc *desc, const void *cons
         cpy32(p[7], L.bo, H, st);
         cpy32(p[8], L.ln1w, H, st);
         cpy32(p[9], L.ln1b, H, st);
+        if (e->split) {
+            const float *gin = (const float *)(i == 0 ? w[3] : w[5 + 16 * (i - 1) + 14]);
+            const float *bin = (const float *)(i == 0 ? w[4] : w[5 + 16 * (i - 1) + 15]);
+            auto sw = [&](const void *W, const void *b, const float *g, const float *be, int N, int K, _Float16 *Wp, float *cs,
+                          float *bo) {
+                hipLaunchKernelGGL(split_weight_kernel, dim3((N + 3) / 4), dim3(256), 0, st, (const float *)W, (const float *)b, g, be,
+                                   N, K, Wp, cs, bo);
+            };
+            sw(p[0], p[1], gin, bin, H, H, L.wqkv_s, L.cqkv_s, L.bqkv_s);                                             // query
+            sw(p[2], p[3], gin, bin, H, H, L.wqkv_s + (size_t)H * HP, L.cqkv_s + H, L.bqkv_s + H);                    // key
+            sw(p[4], p[5], gin, bin, H, H, L.wqkv_s + (size_t)2 * H * HP, L.cqkv_s + 2 * H, L.bqkv_s + 2 * H);        // value
+            sw(p[6], nullptr, nullptr, nullptr, H, H, L.wo_s, nullptr, nullptr);                                      // attention.output.dense
+            sw(p[10], p[11], (const float *)p[8], (const float *)p[9], (int)I, H, L.w1_s, L.c1_s, L.b1_s);            // intermediate.dense
+            sw(p[12], nullptr, nullptr, nullptr, H, (int)I, L.w2_s, nullptr, nullptr);                                // output.dense
+        }
         if (e->precise) {
             cpy32(p[0], L.wqkv32, (size_t)H * H, st);
             cpy32(p[2], L.wqkv32 + (size_t)H * H, (size_t)H * H, st);

@@ -75,7 +75,7 @@ __device__ __forceinline__ void epb_issue(const GemmArgs &G, float *smem_f, int 
     }
     const int f0 = EPI_ == EPI_VT_F ? m0 : n0;    // first of the tile's 256 features
     if (w == 0) __builtin_amdgcn_global_load_lds((glb_t *)(G.bias + f0 + l * 4), (lds_t *)(pb + EPB_VEC), 16, 0, 0);
-    if (EPI_ == EPI_RESLN) {
+    if (EPI_ == EPI_RESLN || EPI_ == EPI_S_RESLN) {
         if (w == 1) __builtin_amdgcn_global_load_lds((glb_t *)(G.res_gamma + f0 + l * 4), (lds_t *)(pb + EPB_VEC + 256), 16, 0, 0);
         if (w == 2) __builtin_amdgcn_global_load_lds((glb_t *)(G.res_beta + f0 + l * 4), (lds_t *)(pb + EPB_VEC + 512), 16, 0, 0);
     } else {
@@ -84,16 +84,21 @@ __device__ __forceinline__ void epb_issue(const GemmArgs &G, float *smem_f, int 
 }
 
 // first step of a folded epilogue (all 512 threads, after the main loop): thread t < 256 combines the slice partials of
-// token t into (mean, rstd); one workgroup barrier publishes them
-__device__ __forceinline__ void epb_stats(const GemmArgs &G, float *smem_f, int tid) {
+// token t into (mean, rstd); one workgroup barrier publishes them.  Returns (uniformly) whether any token of the tile has
+// |mean| rstd > FOLD_WIDE_MEAN: the single-fp16 token operand of the folded GEMMs rounds v, not v - mean, so its error grows
+// with |mean| / std (20-80 x at an offset of 5-30 std); such a tile adds a second pass over the lo halves.
+constexpr float FOLD_WIDE_MEAN = 2.0f;
+__device__ __forceinline__ bool epb_stats(const GemmArgs &G, float *smem_f, int tid) {
     float *pb = smem_f + EPB_OFF;
+    int wide = 0;
     if (tid < 256) {
         float mean, rstd;
         stats_from_parts(pb + EPB_PART + tid * 24, G.ln_eps, &mean, &rstd);
         pb[EPB_STATS + 2 * tid] = mean;
         pb[EPB_STATS + 2 * tid + 1] = rstd;
+        wide = __builtin_fabsf(mean) * rstd > FOLD_WIDE_MEAN;
     }
-    __syncthreads();
+    return __builtin_amdgcn_readfirstlane(__syncthreads_or(wide)) != 0;  // (readfirstlane: the compiler must know it is uniform)
 }
 
 template <int EPI_, bool WAVE_SYNC = false>
@@ -367,6 +372,122 @@ __device__ __forceinline__ void gemm256_epilogue(const GemmArgs &G, f32x16 (&acc
                 const int rr = it * 8 + (l >> 3);
                 const f16x8 v = *reinterpret_cast<const f16x8 *>(slab + rr * LS + c8 * 8);
                 *reinterpret_cast<f16x8 *>(po + it * ostep) = v;
+            }
+        }
+    }
+}
+
+// ---- epilogues of the SPLIT (fp32-grade) GEMM ---------------------------------------------------------------------------
+// exact-erf GELU (the reference's: transformers "gelu" = x Phi(x), erf form), full-precision device erff
+__device__ __forceinline__ float gelu_exact(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+// v -> (hi, lo'): hi = fp16(v), lo' = fp16((v - hi) 2^11).  v - hi is exact in fp32; the scale keeps lo' in the fp16 normal range
+constexpr float SPLIT_SCALE = 2048.0f, SPLIT_INV = 1.0f / 2048.0f;
+__device__ __forceinline__ void split4(const f32x4 v, f16x4 *hi, f16x4 *lo) {
+    const f16x4 h = f16x4{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+    *hi = h;
+    *lo = f16x4{(_Float16)((v[0] - (float)h[0]) * SPLIT_SCALE), (_Float16)((v[1] - (float)h[1]) * SPLIT_SCALE),
+                (_Float16)((v[2] - (float)h[2]) * SPLIT_SCALE), (_Float16)((v[3] - (float)h[3]) * SPLIT_SCALE)};
+}
+
+// One structure for the three of them: 4 passes over the wave's 128 rows, each through the wave-private fp32 slab
+// [32 m][64 n] (as EPI_RES32 / EPI_RESLN), so that on read-back a lane owns 4 consecutive columns of a row and global
+// traffic is whole 16-byte (fp32) or 8-byte (fp16) row segments.
+//   EPI_S_QKV    out32[m][n]         = r (acc - mu c) + b'                   folded LayerNorm, fp32 out (Q | K | V)
+//   EPI_S_GELU   out16 pair [m][n]   = split(gelu_exact(r (acc - mu c) + b'))   row = [hi (N) | lo' (N)], ldc = 2 N
+//   EPI_S_RESLN  out16 pair [m][n]   = split(acc + bias + LayerNorm(res_hi + res_lo' 2^-11)), + slice statistics (part_out)
+template <int EPI>
+__device__ __forceinline__ void gemm256_epilogue_split(const GemmArgs &G, f32x16 (&acc)[2][4], float *smem_f, int m0, int n0,
+                                                       int w, int l) {
+    const int g = l >> 5, i = l & 31;
+    const int wm = w >> 2, wn = w & 3;
+    const int mw0 = m0 + wm * 128, nw0 = n0 + wn * 64;
+    float *slab = smem_f + w * 4096;
+    constexpr int LS = 68;
+    const int c4 = l & 15;
+    const float *pb = smem_f + EPB_OFF;
+    const f32x4 v0 = *reinterpret_cast<const f32x4 *>(pb + EPB_VEC + wn * 64 + c4 * 4);        // bias (b' for the folded ones)
+    const f32x4 v1 = *reinterpret_cast<const f32x4 *>(pb + EPB_VEC + 256 + wn * 64 + c4 * 4);  // csum | gamma
+    f32x4 v2 = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (EPI == EPI_S_RESLN) v2 = *reinterpret_cast<const f32x4 *>(pb + EPB_VEC + 512 + wn * 64 + c4 * 4);  // beta
+    const int n_parts = G.N >> 6, slice = nw0 >> 6;
+#pragma unroll
+    for (int y = 0; y < 4; ++y) {
+        f16x4 rh[8], rl[8];
+        float mean[8], rstd[8];
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int rr = it * 4 + (l >> 4);
+            if constexpr (EPI == EPI_S_RESLN) {
+                const _Float16 *rp = G.res_hi + (size_t)(mw0 + y * 32 + rr) * G.ldr + nw0 + c4 * 4;
+                rh[it] = *reinterpret_cast<const f16x4 *>(rp);
+                rl[it] = *reinterpret_cast<const f16x4 *>(rp + G.N);
+            }
+            mean[it] = pb[EPB_STATS + 2 * (wm * 128 + y * 32 + rr)];
+            rstd[it] = pb[EPB_STATS + 2 * (wm * 128 + y * 32 + rr) + 1];
+        }
+        epi_sync<true>();
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                const f32x16 &a = acc[x][y];
+                *reinterpret_cast<f32x4 *>(slab + i * LS + x * 32 + 8 * rq + 4 * g) =
+                    f32x4{a[4 * rq], a[4 * rq + 1], a[4 * rq + 2], a[4 * rq + 3]};
+            }
+        epi_sync<true>();
+        const size_t row0 = (size_t)(mw0 + y * 32 + (l >> 4));
+        f32x4 vv[8];
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int rr = it * 4 + (l >> 4);
+            f32x4 v = *reinterpret_cast<const f32x4 *>(slab + rr * LS + c4 * 4);
+            const size_t row = row0 + (size_t)it * 4;
+            if constexpr (EPI == EPI_S_RESLN) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float a = rstd[it] * v1[e];
+                    const float res = (float)rh[it][e] + (float)rl[it][e] * SPLIT_INV;  // exact in fp32: 22 bits
+                    v[e] += __builtin_fmaf(res - mean[it], a, v0[e] + v2[e]);
+                }
+                f16x4 hi, lo;
+                split4(v, &hi, &lo);
+                _Float16 *op = G.out16 + row * G.ldc + nw0 + c4 * 4;
+                *reinterpret_cast<f16x4 *>(op) = hi;
+                *reinterpret_cast<f16x4 *>(op + G.N) = lo;
+                vv[it] = v;
+            } else {
+                const float mr = mean[it] * rstd[it];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(v[e], rstd[it], __builtin_fmaf(-mr, v1[e], v0[e]));
+                if constexpr (EPI == EPI_S_QKV) {
+                    *reinterpret_cast<f32x4 *>(G.out32 + row * G.ldc + nw0 + c4 * 4) = v;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = gelu_exact(v[e]);
+                    f16x4 hi, lo;
+                    split4(v, &hi, &lo);
+                    _Float16 *op = G.out16 + row * G.ldc + nw0 + c4 * 4;
+                    *reinterpret_cast<f16x4 *>(op) = hi;
+                    *reinterpret_cast<f16x4 *>(op + G.N) = lo;
+                }
+            }
+        }
+        if constexpr (EPI == EPI_S_RESLN) {
+            float s8[8], q8[8];
+#pragma unroll
+            for (int it = 0; it < 8; ++it) s8[it] = row16_sum((vv[it][0] + vv[it][1]) + (vv[it][2] + vv[it][3])) * (1.0f / 64.0f);
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const float m64 = s8[it];
+                const float d0 = vv[it][0] - m64, d1 = vv[it][1] - m64, d2 = vv[it][2] - m64, d3 = vv[it][3] - m64;
+                q8[it] = row16_sum((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3));
+            }
+            if (c4 == 0) {
+                float *pp = G.part_out + (row0 * n_parts + slice) * 2;
+                const size_t pstep = (size_t)4 * n_parts * 2;
+#pragma unroll
+                for (int it = 0; it < 8; ++it) *reinterpret_cast<float2 *>(pp + it * pstep) = make_float2(s8[it], q8[it]);
             }
         }
     }

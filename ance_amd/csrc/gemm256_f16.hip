@@ -147,21 +147,39 @@ __device__ unsigned long long *g_gemm_stamps = nullptr;
 #define GSTAMP(slot) do { } while (0)
 #endif
 
-template <int EPI>
-__global__ void __launch_bounds__(G256_THREADS, 2) gemm256_f16_desc_kernel(const GemmArgs G) {
-    extern __shared__ __attribute__((aligned(16))) float smem_f[];
-    _Float16 *smem = reinterpret_cast<_Float16 *>(smem_f);
+// XCD-aware tile order (speed only).  Blocks b, b + 8, ... share an XCD (and its 4 MiB L2).  The dimension with more tiles
+// is dealt round-robin to the XCDs, the other one is swept fastest, so the panel of the outer dimension stays in that XCD's L2
+// while the inner panels stream through it.  N-SPLIT (round 4): when the inner dimension's operand does not fit the L2 -- FFN1:
+// 12 weight tiles x 384 KiB = 4.5 MiB, re-fetched for every token panel: 994 MB of L2 fills + writes per launch against
+// 510 MB algorithmic (profiles/pmc_traffic.json, r03) -- the XCDs pair up: XCD x sweeps only the N-tiles of half x & 1 (2.25 MiB,
+// resident) for the token panels = x >> 1 (mod 4).  A token panel is then fetched by two XCDs instead of one, the weights
+// by every XCD once.
+__device__ __forceinline__ bool tile_of_block(const GemmArgs &G, int b, int *mt_, int *nt_) {
     const int NT = G.N / TN, MT = G.M / TM;
-    const int b = blockIdx.x, xcd = b & 7, jx = b >> 3;  // XCD-aware tile order: see gemm256_f16_kernel
+    const int xcd = b & 7, jx = b >> 3;
     int mt, nt;
-    if (MT >= NT) {
+    if (G.n_split == 2) {
+        const int nh = NT >> 1;
+        mt = (jx / nh) * 4 + (xcd >> 1);
+        nt = (xcd & 1) * nh + jx % nh;
+    } else if (MT >= NT) {
         mt = (jx / NT) * 8 + xcd;
         nt = jx % NT;
     } else {
         nt = (jx / MT) * 8 + xcd;
         mt = jx % MT;
     }
-    if (mt >= MT || nt >= NT) return;
+    *mt_ = mt;
+    *nt_ = nt;
+    return mt < MT && nt < NT;
+}
+
+template <int EPI>
+__global__ void __launch_bounds__(G256_THREADS, 2) gemm256_f16_desc_kernel(const GemmArgs G) {
+    extern __shared__ __attribute__((aligned(16))) float smem_f[];
+    _Float16 *smem = reinterpret_cast<_Float16 *>(smem_f);
+    int mt, nt;
+    if (!tile_of_block(G, blockIdx.x, &mt, &nt)) return;
     const int m0 = mt * TM, n0 = nt * TN;
     const int tid = threadIdx.x;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -190,9 +208,28 @@ __global__ void __launch_bounds__(G256_THREADS, 2) gemm256_f16_desc_kernel(const
 #endif
     GSTAMP(0);
     if constexpr (EPB) epb_issue<EPI>(G, smem_f, m0, n0, w, l);
-    P.run(G.K / TK, acc);
-    GSTAMP(1);
-    if constexpr (EPB) epb_stats(G, smem_f, tid);
+    constexpr bool FOLDK = EPI == EPI_QK_F || EPI == EPI_GELU_F || EPI == EPI_VT_F;
+    if constexpr (FOLDK) {
+        // ONE copy of the main loop, entered a second time only by a tile with a token whose |mean| >> std: that pass adds
+        // lo . W^T (the K loop over the lo halves of the token operand; the identity  r (acc - mu c) + b'  holds for any
+        // operand, so nothing else changes).  Uniform branch, taken by no tile of a random-init model.
+#pragma nounroll
+        for (int pass = 0;; ++pass) {
+            P.run(G.K / TK, acc);
+            if (pass) break;
+            GSTAMP(1);
+            const bool wide = epb_stats(G, smem_f, tid);
+            if (!(wide && G.tok_lo)) break;
+            if constexpr (EPI == EPI_VT_F)
+                P.S.rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16 *>(G.tok_lo + (size_t)n0 * G.ldb), 0, (int)(256u * (uint32_t)G.ldb * 2u), 0x00020000);
+            else
+                P.S.ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16 *>(G.tok_lo + (size_t)m0 * G.lda), 0, (int)(256u * (uint32_t)G.lda * 2u), 0x00020000);
+        }
+    } else {
+        P.run(G.K / TK, acc);
+        GSTAMP(1);
+        if constexpr (EPB) (void)epb_stats(G, smem_f, tid);
+    }
     GSTAMP(2);
 #ifdef ANCE_MEASURE
     gemm256_epilogue<EPI, true>(G, acc, smem_f, m0, n0, w, l, stamps_ ? stamps_ + (size_t)blockIdx.x * 8 + 4 : nullptr);
@@ -201,6 +238,57 @@ __global__ void __launch_bounds__(G256_THREADS, 2) gemm256_f16_desc_kernel(const
     gemm256_epilogue<EPI, true>(G, acc, smem_f, m0, n0, w, l);
 #endif
     GSTAMP(3);
+}
+
+// SPLIT (fp32-grade) GEMM: C = A B^T with both operands as fp16 (hi, lo') pairs (rows [hi (K) | lo' (K)], v = hi + lo' 2^-11),
+//   C = 2^-11 (A_lo' B_hi^T + A_hi B_lo'^T) + A_hi B_hi^T
+// on the same 256 x 256 x 64 ping-pong pipeline: 3 K / 64 K-tiles in one stream (PipeSrcSplit moves the SGPR offset of the
+// LDS-DMA from segment to segment), one multiplication of the 128 accumulator registers by 2^-11 after the two correction
+// segments.  Every partial product is exact in fp32 (11 x 11 bits), the dropped lo' x lo' term is 2^-22 relative: an
+// fp32-grade result at a third of the fp16 MFMA rate (the fp32-input matrix cores run at a sixteenth).  tests/test_split_model.py
+// restates the rounding points on the CPU (3.3e-6 against the fp64 oracle at 12 layers; plain fp32: 2.8e-6).
+template <int EPI>
+__global__ void __launch_bounds__(G256_THREADS, 2) gemm256_split_kernel(const GemmArgs G) {
+    extern __shared__ __attribute__((aligned(16))) float smem_f[];
+    _Float16 *smem = reinterpret_cast<_Float16 *>(smem_f);
+    int mt, nt;
+    if (!tile_of_block(G, blockIdx.x, &mt, &nt)) return;
+    const int m0 = mt * TM, n0 = nt * TN;
+    const int tid = threadIdx.x;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l = tid & 63;
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 4; ++y) acc[x][y] = f32x16{0};
+    Pipe256T<PipeSrcSplit, false, true, true> P;
+    P.init(smem, w, l);
+    P.S.ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16 *>(G.A + (size_t)m0 * G.lda), 0, (int)(256u * (uint32_t)G.lda * 2u), 0x00020000);
+    P.S.rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16 *>(G.B + (size_t)n0 * G.ldb), 0, (int)(256u * (uint32_t)G.ldb * 2u), 0x00020000);
+    const int NK = G.K / TK;
+    P.S.nk = NK;
+    P.S.kbytes = G.K * 2;
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int r = pipe_stage_row(w, l, j), ch = pipe_stage_chunk(r, l);
+            P.S.voff[h][j] = (uint32_t)(pipe_a_tile_row(h, r) * G.lda + ch) * 2u;
+            P.S.voff[2 + h][j] = (uint32_t)(pipe_b_tile_row(h, r) * G.ldb + ch) * 2u;
+        }
+    epb_issue<EPI>(G, smem_f, m0, n0, w, l);
+    P.prologue();
+    P.enter();
+    P.tiles_streaming(2 * NK, acc);   // the two correction segments (both carry the factor 2^11)
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 4; ++y) acc[x][y] *= SPLIT_INV;
+    P.tiles_final(3 * NK, acc, 2 * NK);  // hi x hi
+    P.leave();
+    (void)epb_stats(G, smem_f, tid);
+    gemm256_epilogue_split<EPI>(G, acc, smem_f, m0, n0, w, l);
 }
 
 template <int EPI, bool ABLATE>
@@ -284,7 +372,13 @@ unsigned long long *g_gemm_stamps_host = nullptr;
 template <bool ABLATE>
 int launch256(int epi, const GemmArgs &G, hipStream_t st) {
     const int MT = G.M / TM, NT = G.N / TN;
-    const unsigned blocks = MT >= NT ? (unsigned)((MT + 7) / 8 * 8) * (unsigned)NT : (unsigned)((NT + 7) / 8 * 8) * (unsigned)MT;
+    if (G.n_split != 0 && (G.n_split != 2 || (NT & 1) || ABLATE || epi < EPI_RESLN)) {
+        set_last_error("gemm256: n_split needs an even number of N tiles and a descriptor-form kernel");
+        return ANCE_E_INVALID;
+    }
+    const unsigned blocks = G.n_split == 2 ? (unsigned)((MT + 3) / 4 * 4) * (unsigned)NT
+                            : MT >= NT     ? (unsigned)((MT + 7) / 8 * 8) * (unsigned)NT
+                                           : (unsigned)((NT + 7) / 8 * 8) * (unsigned)MT;
     void (*k)(const GemmArgs) = nullptr;
     static int use_desc = -1;
     if (use_desc < 0) {
@@ -301,19 +395,19 @@ int launch256(int epi, const GemmArgs &G, hipStream_t st) {
         case EPI_QK_F: k = gemm256_f16_desc_kernel<EPI_QK_F>; break;
         case EPI_GELU_F: k = gemm256_f16_desc_kernel<EPI_GELU_F>; break;
         case EPI_VT_F: k = gemm256_f16_desc_kernel<EPI_VT_F>; break;
+        case EPI_S_QKV: k = gemm256_split_kernel<EPI_S_QKV>; break;
+        case EPI_S_GELU: k = gemm256_split_kernel<EPI_S_GELU>; break;
+        case EPI_S_RESLN: k = gemm256_split_kernel<EPI_S_RESLN>; break;
         default: set_last_error("gemm256: bad epilogue"); return ANCE_E_INVALID;
     }
     // the dynamic-LDS attribute is per template instance AND per device
     static unsigned long long attr_done[2 * EPI_COUNT] = {0};
     const int ai = epi + ((desc || epi >= EPI_RESLN) ? EPI_COUNT : 0);
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    const unsigned long long dbit = 1ull << (dev & 63);
-    if (!(attr_done[ai] & dbit)) {
+    if (attr_needed(&attr_done[ai])) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)(G256_LDS_BYTES + (size_t)EPB_FLOATS * sizeof(float))) != hipSuccess)
             return check_launch("gemm256 attr");
-        attr_done[ai] |= dbit;
+        attr_mark(&attr_done[ai]);
     }
     const size_t lds = epi >= EPI_RESLN ? G256_LDS_BYTES + (size_t)EPB_FLOATS * sizeof(float) : G256_LDS_BYTES;
 #ifdef ANCE_MEASURE

@@ -278,6 +278,7 @@ int launch_finalize_keys(const u64 *keys, int64_t nq, int m, int k, int64_t row_
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(topk_finalize_kernel<false>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)(8192 * sizeof(u64))) != hipSuccess)
             return check_launch("topk_finalize attr");
+        attr_mark(&attr_done);
     }
     ProfScope pf(PC_FINALIZE, st);
     hipLaunchKernelGGL(topk_finalize_kernel<false>, dim3((unsigned)nq), dim3(256), P2 * sizeof(u64), st, keys,
@@ -296,6 +297,7 @@ int launch_reduce_keys(const u64 *keys, int nq_max, int m, int k, u64 *out, cons
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(topk_reduce_keys_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)(8192 * sizeof(u64))) != hipSuccess)
             return check_launch("topk_reduce_keys attr");
+        attr_mark(&attr_done);
     }
     hipLaunchKernelGGL(topk_reduce_keys_kernel, dim3((unsigned)nq_max), dim3(256), P2 * sizeof(u64), st, keys, m, P2, k, out, nq_dev);
     return ANCE_OK;
@@ -311,6 +313,7 @@ int launch_scan(const Plan &pl, const float *d_x, int64_t n, const float *q, int
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(scan), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)SCAN_LDS_BYTES) != hipSuccess)
             return check_launch("ip_topk_scan attr");
+        attr_mark(&attr_done[ai]);
     }
     ScanParams P;
     P.x = d_x; P.q = q; P.n = (uint32_t)n; P.nq = (uint32_t)nqc; P.d = d; P.k = k; P.S = pl.S;

@@ -1292,6 +1292,7 @@ int ip_topk_fast(const float *d_x, int64_t n, int64_t row_base, const void *d_in
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(rescore_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)rescore_lds_bytes(F_MAX_D)) != hipSuccess)
             return check_launch("rescore attr");
+        attr_mark(&attr_done);
     }
     EpsConst eps;
     eps.rel_c = 1.25f * (9.765625e-4f + 1.1f * d * 5.9604645e-8f);

@@ -107,6 +107,7 @@ int launch_gemm32(int epi, const float *A, int lda, const float *B, int ldb, con
     if (attr_needed(&attr_done[epi])) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)P_GEMM_LDS) != hipSuccess)
             return check_launch("gemm32 attr");
+        attr_mark(&attr_done[epi]);
     }
     hipLaunchKernelGGL(k, dim3(N / P_TN, M / P_TM), dim3(256), P_GEMM_LDS, st, A, lda, B, ldb, bias, res, ldr, out, ldc, K);
     return ANCE_OK;
@@ -180,16 +181,21 @@ __global__ void __launch_bounds__(256) embed32_kernel(const int *tok_id, const i
 constexpr int P_KC = 128;
 constexpr size_t P_ATT_LDS = (size_t)2 * P_KC * 64 * sizeof(float);
 
-__global__ void __launch_bounds__(256) attention32_kernel(const float *qkv, float *ctx, const int *seq_off, int n_heads) {
+// ctx_pair != null (split mode, encoder.hip): the output row is written as an fp16 pair [hi (768) | lo' (768)],
+// lo' = fp16((v - hi) 2^11), the token operand of the split attention-output GEMM; cls_only: only query 0 of every sequence is
+// computed and its row goes to row s (compact), as in attention.hip.
+__global__ void __launch_bounds__(256) attention32_kernel(const float *qkv, float *ctx, _Float16 *ctx_pair, int cls_only,
+                                                          const int *seq_off, int n_heads) {
     extern __shared__ __attribute__((aligned(16))) float smem_p[];
     float *Ks = smem_p, *Vs = smem_p + P_KC * 64;
     const int s = blockIdx.x / n_heads, h = blockIdx.x - s * n_heads;
     const int tok0 = seq_off[s], T = seq_off[s + 1] - tok0;
     const int tid = threadIdx.x;
     const int ld = 3 * 768;
-    for (int q0 = 0; q0 < T; q0 += 256) {
+    const int q_end = cls_only ? 1 : T;
+    for (int q0 = 0; q0 < q_end; q0 += 256) {
         const int qi = q0 + tid;
-        const bool qv = qi < T;
+        const bool qv = qi < q_end;
         float q[64], acc[64];
         float m = -INFINITY, lsum = 0.f;
         {
@@ -227,21 +233,40 @@ __global__ void __launch_bounds__(256) attention32_kernel(const float *qkv, floa
         }
         if (qv) {
             const float inv = 1.0f / lsum;
-            float *op = ctx + (size_t)(tok0 + qi) * 768 + h * 64;
+            const size_t orow = cls_only ? (size_t)s : (size_t)(tok0 + qi);
+            if (ctx_pair) {
+                _Float16 *ph = ctx_pair + orow * 1536 + h * 64;
 #pragma unroll
-            for (int d = 0; d < 64; ++d) op[d] = acc[d] * inv;
+                for (int d = 0; d < 64; d += 4) {
+                    f16x4 hi, lo;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float v = acc[d + e] * inv;
+                        hi[e] = (_Float16)v;
+                        lo[e] = (_Float16)((v - (float)hi[e]) * 2048.0f);
+                    }
+                    *reinterpret_cast<f16x4 *>(ph + d) = hi;
+                    *reinterpret_cast<f16x4 *>(ph + 768 + d) = lo;
+                }
+            } else {
+                float *op = ctx + orow * 768 + h * 64;
+#pragma unroll
+                for (int d = 0; d < 64; ++d) op[d] = acc[d] * inv;
+            }
         }
     }
 }
 
-int launch_attention32(const float *qkv, float *ctx, const int *seq_off, int n_seq, int n_heads, hipStream_t st) {
+int launch_attention32(const float *qkv, float *ctx, const int *seq_off, int n_seq, int n_heads, hipStream_t st,
+                       _Float16 *ctx_pair = nullptr, int cls_only = 0) {
     static unsigned long long attr_done = 0;
     if (attr_needed(&attr_done)) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(attention32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)P_ATT_LDS) != hipSuccess)
             return check_launch("attention32 attr");
+        attr_mark(&attr_done);
     }
-    hipLaunchKernelGGL(attention32_kernel, dim3((unsigned)n_seq * n_heads), dim3(256), P_ATT_LDS, st, qkv, ctx, seq_off, n_heads);
+    hipLaunchKernelGGL(attention32_kernel, dim3((unsigned)n_seq * n_heads), dim3(256), P_ATT_LDS, st, qkv, ctx, ctx_pair, cls_only, seq_off, n_heads);
     return ANCE_OK;
 }
 

@@ -181,9 +181,17 @@ typedef struct AnceEncoder AnceEncoder;
  * Arithmetic.  Default: fp16 MFMA operands, fp32 accumulation, fp32 softmax / statistics / head; LayerNorm folded into the
  * GEMMs and the residual stream kept as fp16 (hi, lo) pairs (22 mantissa bits) -- max |delta| 3e-3 on unit-variance
  * embeddings against the reference's fp32 arithmetic (stated tolerance of the tests: 5e-3).
- * Environment, read when a handle is created (the two size queries read ANCE_ENCODER_PRECISE as well):
+ * Input-distribution precondition of the default mode: a folded GEMM takes fp16(v) of the PRE-LayerNorm row v as its token
+ * operand, so its rounding error scales with |v|, not |v - mean|.  A GEMM tile with a token whose |mean| rstd exceeds 2
+ * therefore runs a second K loop over the lo halves on its own (22-bit operand, no host involvement); below that threshold the
+ * error is at most sqrt(1 + 2^2) x the random-init figure.  Pre-LayerNorm values must stay below 65,504 (fp16 range).
+ * Environment, read when a handle is created (the two size queries read ANCE_ENCODER_PRECISE / ANCE_ENCODER_SPLIT as well):
+ *   ANCE_ENCODER_SPLIT=1     split mode: an fp32-GRADE result from the fp16 matrix cores -- every GEMM operand an fp16 pair
+ *                            v = hi + lo' 2^-11, three MFMA passes per product (hi lo' + lo' hi, rescale, hi hi), fp32 softmax,
+ *                            exact erf GELU, fp32 head; max |delta| 2e-5 (stated), ~3 x slower than the default
  *   ANCE_ENCODER_PRECISE=1   fp32 mode: fp32 operands on the fp32-input matrix cores, exact erf GELU, fp32 softmax -- the
- *                            reference's arithmetic (model/models.py:149-157); max |delta| 1e-5, ~9 x slower
+ *                            reference's arithmetic (model/models.py:149-157); max |delta| 1e-5, ~9 x slower (the audit path)
+ *   ANCE_GEMM_NSPLIT=0       FFN1 without the N-split tile order (A/B switch)
  *   ANCE_ENCODER_STREAMS=n   internal streams / activation sets (1 or 2, default 2)
  *   ANCE_LN_FOLD=0 ANCE_HEAD_MFMA=0 ANCE_CLS_TAIL=0 ANCE_ATTN_COAL=0 ANCE_GEMM_DESC=0   A/B switches back to the previous
  *                            form of one piece each (LayerNorm kernels, per-sequence head, full last layer, per-lane

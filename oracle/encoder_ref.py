@@ -151,3 +151,94 @@ def random_state_dict(kind="roberta", n_layers=12, hidden=768, inter=3072, vocab
         sd["norm.weight"] = torch.ones(768) + ln_jitter * torch.randn(768, generator=g)
         sd["norm.bias"] = ln_jitter * torch.randn(768, generator=g)
     return sd
+
+
+# ---- deterministic weights that do not depend on any library's random stream ---------------------------------
+# The golden vectors of the reference's own classes (tests/golden/) are only as durable as the weights they were
+# generated with.  ``random_state_dict`` draws from torch's generator, whose stream another torch build may change
+# (the pinned tests then degrade to skips).  ``det_state_dict`` has the same structure but draws every tensor from a
+# counter-based generator written out here: splitmix64 of (element index, seed, crc32 of the tensor name) -> four
+# 16-bit uniforms -> their sum (Irwin-Hall, n = 4: variance 1/3) -> scaled to the requested std.  Integer arithmetic
+# mod 2^64, one exact int -> float64 conversion, one float64 multiply, one cast to float32: bit-identical on every
+# IEEE-754 platform and every NumPy / torch version.
+_SM_GOLDEN = 0x9E3779B97F4A7C15
+_SM_M1 = 0xBF58476D1CE4E5B9
+_SM_M2 = 0x94D049BB133111EB
+_IH4_SCALE = 1.7320508075688772 / 65536.0  # sqrt(3) / 2^16: unit variance for the centred sum of four 16-bit uniforms
+
+
+def det_normal(seed, name, shape, std=1.0):
+    """float32 numpy array of ``shape``, mean 0, standard deviation ``std`` (bell-shaped, |x| <= 3.47 std)."""
+    import zlib
+
+    import numpy as np
+    n = 1
+    for s in shape:
+        n *= int(s)
+    key = (int(seed) * 0xD1342543DE82EF95 + zlib.crc32(name.encode("utf8")) * 0x2545F4914F6CDD1D + 0x632BE59BD9B4E019) & (2 ** 64 - 1)
+    out = np.empty(n, dtype=np.float32)
+    step = 1 << 22
+    for a in range(0, n, step):
+        z = np.arange(a, min(n, a + step), dtype=np.uint64)
+        z = z * np.uint64(_SM_GOLDEN) + np.uint64(key)
+        z ^= z >> np.uint64(30)
+        z *= np.uint64(_SM_M1)
+        z ^= z >> np.uint64(27)
+        z *= np.uint64(_SM_M2)
+        z ^= z >> np.uint64(31)
+        m = np.uint64(0xFFFF)
+        s4 = (z & m) + ((z >> np.uint64(16)) & m) + ((z >> np.uint64(32)) & m) + (z >> np.uint64(48))
+        v = (s4.astype(np.float64) - 131070.0) * (_IH4_SCALE * float(std))
+        out[a:a + len(v)] = v.astype(np.float32)
+    return out.reshape(shape)
+
+
+def det_state_dict(kind="roberta", n_layers=12, hidden=768, inter=3072, vocab=50265, max_pos=514, seed=0, head=True,
+                   prefixes=("roberta.",), std=0.02, ln_jitter=0.0):
+    """``random_state_dict`` with ``det_normal`` as the generator (same names, shapes, init scale: normal-like std 0.02 for
+    Linear / Embedding weights, model/models.py:31-36; LayerNorm weight 1 + jitter, biases jitter)."""
+    sd = {}
+
+    def put(name, shape, s, base=0.0):
+        t = torch.from_numpy(det_normal(seed, name, shape, s)) if s > 0 else torch.zeros(*shape)
+        sd[name] = t + base if base else t
+
+    def ln(name):
+        put(name + ".weight", (hidden,), ln_jitter, 1.0)
+        put(name + ".bias", (hidden,), ln_jitter)
+
+    def lin(name, out_f, in_f):
+        put(name + ".weight", (out_f, in_f), std)
+        put(name + ".bias", (out_f,), ln_jitter)
+
+    for prefix in prefixes:
+        e = prefix + "embeddings."
+        put(e + "word_embeddings.weight", (vocab, hidden), std)
+        put(e + "position_embeddings.weight", (max_pos, hidden), std)
+        put(e + "token_type_embeddings.weight", (1 if kind == "roberta" else 2, hidden), std)
+        ln(e + "LayerNorm")
+        for i in range(n_layers):
+            p = "%sencoder.layer.%d." % (prefix, i)
+            lin(p + "attention.self.query", hidden, hidden)
+            lin(p + "attention.self.key", hidden, hidden)
+            lin(p + "attention.self.value", hidden, hidden)
+            lin(p + "attention.output.dense", hidden, hidden)
+            ln(p + "attention.output.LayerNorm")
+            lin(p + "intermediate.dense", inter, hidden)
+            lin(p + "output.dense", hidden, inter)
+            ln(p + "output.LayerNorm")
+    if head:
+        lin("embeddingHead", 768, hidden)
+        put("norm.weight", (768,), ln_jitter, 1.0)
+        put("norm.bias", (768,), ln_jitter)
+    return sd
+
+
+def state_dict_sha256(sd):
+    """Content hash of a weight dict (names + raw float32 bytes): what the golden manifests record."""
+    import hashlib
+    h = hashlib.sha256()
+    for k in sorted(sd):
+        h.update(k.encode("utf8"))
+        h.update(sd[k].detach().cpu().contiguous().numpy().astype("<f4").tobytes())
+    return h.hexdigest()

@@ -6,7 +6,9 @@
 The reference ships no tests or fixtures of its own, so these vectors are what
 pins the oracle: they are outputs of the reference's own classes / functions on seeded inputs.
 Weights are not stored (a RoBERTa embedding table is 154 MB): they are regenerated from
-``oracle.encoder_ref.random_state_dict(seed)`` and a checksum in the fixture detects an RNG drift.
+``oracle.encoder_ref.det_state_dict(seed)`` -- a counter-based generator written out in the oracle (integer hashing +
+exact float conversions), so the weights do not depend on any torch / NumPy random stream -- and the manifest records
+their sha256.
 """
 import json
 import os
@@ -26,8 +28,7 @@ OUT = os.path.dirname(os.path.abspath(__file__))
 
 
 def sd_checksum(sd):
-    keys = sorted(sd.keys())
-    return float(sum(sd[k].double().abs().sum().item() for k in keys[:: max(1, len(keys) // 16)]))
+    return encoder_ref.state_dict_sha256(sd)
 
 
 def load_into(model, sd):
@@ -40,7 +41,7 @@ def golden_encoder():
     rng = np.random.default_rng(2024)
     out = {}
     # FirstP / query encoder (model/models.py:149-157), 2 layers, non-trivial LN/bias parameters
-    sd = encoder_ref.random_state_dict(seed=11, n_layers=2, ln_jitter=0.1)
+    sd = encoder_ref.det_state_dict(seed=11, n_layers=2, ln_jitter=0.1)
     m = ref_harness.build_reference_model("rdot_nll", n_layers=2, seed=0)
     load_into(m, sd)
     L = 128
@@ -48,22 +49,22 @@ def golden_encoder():
     ids = synth.make_records(rng, len(lens), L, lens.astype(np.int64))
     with torch.no_grad():
         emb = m.body_emb(torch.from_numpy(ids).long(), encoder_ref.mask_from_lengths(lens, L))
-    out["firstp"] = dict(seed=11, n_layers=2, ln_jitter=0.1, checksum=sd_checksum(sd))
+    out["firstp"] = dict(gen="det", seed=11, n_layers=2, ln_jitter=0.1, checksum=sd_checksum(sd))
     np.savez_compressed(os.path.join(OUT, "encoder_firstp.npz"), ids=ids, lens=lens, emb=emb.numpy())
 
     # MaxP body encoder (model/models.py:165-199): 4 x 512 chunks incl. all-pad chunks
-    sd2 = encoder_ref.random_state_dict(seed=12, n_layers=1, ln_jitter=0.05)
+    sd2 = encoder_ref.det_state_dict(seed=12, n_layers=1, ln_jitter=0.05)
     m2 = ref_harness.build_reference_model("rdot_nll_multi_chunk", n_layers=1, seed=0)
     load_into(m2, sd2)
     lens2 = np.array([2048, 1500, 513, 512, 40, 1025], dtype=np.int32)
     ids2 = synth.make_records(rng, len(lens2), 2048, lens2.astype(np.int64))
     with torch.no_grad():
         emb2 = m2.body_emb(torch.from_numpy(ids2).long(), encoder_ref.mask_from_lengths(lens2, 2048))
-    out["maxp"] = dict(seed=12, n_layers=1, ln_jitter=0.05, checksum=sd_checksum(sd2))
+    out["maxp"] = dict(gen="det", seed=12, n_layers=1, ln_jitter=0.05, checksum=sd_checksum(sd2))
     np.savez_compressed(os.path.join(OUT, "encoder_maxp.npz"), ids=ids2, lens=lens2, emb=emb2.numpy())
 
     # DPR / BERT tower (model/models.py:223-259): raw [CLS]
-    sd3 = encoder_ref.random_state_dict(kind="bert", seed=13, n_layers=2, vocab=30522, max_pos=512, head=False,
+    sd3 = encoder_ref.det_state_dict(kind="bert", seed=13, n_layers=2, vocab=30522, max_pos=512, head=False,
                                         prefixes=("ctx_model.",), ln_jitter=0.1)
     m3 = ref_harness.build_reference_model("bert", n_layers=2, seed=0)
     load_into(m3, {k[len("ctx_model."):]: v for k, v in sd3.items()})
@@ -76,8 +77,20 @@ def golden_encoder():
     with torch.no_grad():
         t = torch.from_numpy(ids3).long()
         emb3 = m3(t, (t != 0).long())[1]
-    out["bert"] = dict(seed=13, n_layers=2, ln_jitter=0.1, checksum=sd_checksum(sd3))
+    out["bert"] = dict(gen="det", seed=13, n_layers=2, ln_jitter=0.1, checksum=sd_checksum(sd3))
     np.savez_compressed(os.path.join(OUT, "encoder_bert.npz"), ids=ids3, lens=lens3, emb=emb3.numpy())
+
+    # FULL DEPTH: RobertaDot_NLL_LN.body_emb itself (model/models.py:149-157) at roberta-base's 12 layers -- the depth every
+    # headline number is quoted at; lengths 1, L and the 32 / 64 / 96 tile edges
+    sd4 = encoder_ref.det_state_dict(seed=14, n_layers=12, ln_jitter=0.1)
+    m4 = ref_harness.build_reference_model("rdot_nll", n_layers=12, seed=0)
+    load_into(m4, sd4)
+    lens4 = np.array([1, 2, 31, 32, 33, 63, 64, 65, 96, 97, 127, 128, 128, 70, 9, 50], dtype=np.int32)
+    ids4 = synth.make_records(rng, len(lens4), L, lens4.astype(np.int64))
+    with torch.no_grad():
+        emb4 = m4.body_emb(torch.from_numpy(ids4).long(), encoder_ref.mask_from_lengths(lens4, L))
+    out["firstp12"] = dict(gen="det", seed=14, n_layers=12, ln_jitter=0.1, checksum=sd_checksum(sd4))
+    np.savez_compressed(os.path.join(OUT, "encoder_firstp12.npz"), ids=ids4, lens=lens4, emb=emb4.numpy())
     return out
 
 
@@ -124,7 +137,7 @@ def golden_end_to_end():
     try:
         data = os.path.join(tmp, "data")
         synth.make_msmarco_like(data, n_passages=400, n_train=60, n_dev=20, L=64, Lq=32, seed=77)
-        sd = encoder_ref.random_state_dict(seed=21, n_layers=2, ln_jitter=0.1)
+        sd = encoder_ref.det_state_dict(seed=21, n_layers=2, ln_jitter=0.1)
         m = ref_harness.build_reference_model("rdot_nll", n_layers=2, seed=0)
         load_into(m, sd)
         outd = os.path.join(tmp, "out")
@@ -137,7 +150,7 @@ def golden_end_to_end():
         with open(os.path.join(outd, "ann_ndcg_0")) as f:
             nd = json.load(f)
         with open(os.path.join(OUT, "e2e_toy.json"), "w") as f:
-            json.dump(dict(weights=dict(seed=21, n_layers=2, ln_jitter=0.1, checksum=sd_checksum(sd)),
+            json.dump(dict(weights=dict(gen="det", seed=21, n_layers=2, ln_jitter=0.1, checksum=sd_checksum(sd)),
                            data=dict(n_passages=400, n_train=60, n_dev=20, L=64, Lq=32, seed=77),
                            args=dict(max_seq_length=64, max_query_length=32, topk_training=40, negative_sample=6,
                                      ann_chunk_factor=2, ann_measure_topk_mrr=True, seed=5, output_num=0,
@@ -161,7 +174,7 @@ def golden_end_to_end_maxp():
         dargs = dict(n_passages=56, n_train=24, n_dev=8, L=2048, Lq=32, seed=79, len_median=250, len_sigma=1.1, dup_frac=0.0)
         synth.make_msmarco_like(data, **dargs)
         wargs = dict(seed=23, n_layers=1, ln_jitter=0.1)
-        sd = encoder_ref.random_state_dict(**wargs)
+        sd = encoder_ref.det_state_dict(**wargs)
         m = ref_harness.build_reference_model("rdot_nll_multi_chunk", n_layers=1, seed=0)
         load_into(m, sd)
         outd = os.path.join(tmp, "out")
@@ -174,10 +187,87 @@ def golden_end_to_end_maxp():
         with open(os.path.join(outd, "ann_ndcg_0")) as f:
             nd = json.load(f)
         with open(os.path.join(OUT, "e2e_maxp.json"), "w") as f:
-            json.dump(dict(weights=dict(checksum=sd_checksum(sd), **wargs), data=dargs,
+            json.dump(dict(weights=dict(gen="det", checksum=sd_checksum(sd), **wargs), data=dargs,
                            args=dict(seed=5, output_num=0, checkpoint_path="/x/checkpoint-100/", per_gpu_eval_batch_size=16, **jargs),
                            ann_training_data_0=lines, ann_ndcg_0=nd, result=[res[0], res[1]]), f)
         return dict(ndcg=nd["ndcg"], lines=lines.count("\n"))
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def golden_config1():
+    """BASELINE.json configs[0] at its stated size: the reference's own generate_new_ann
+    (drivers/run_ann_data_gen.py:231-336) on 10,000 passages / 1,000 train / 200 dev queries, L = 128, Lq = 64, roberta-base
+    depth (12 layers), top-200, 20 negatives, 1 % planted duplicate passages -- twice: (a) --ann_measure_topk_mrr (the
+    deterministic selection), ann_chunk_factor 1; (b) the default selection (random.shuffle under random.seed(0)),
+    ann_chunk_factor 5, output_num 2 (third query chunk).  The stand-in faiss index records what the reference asked of it
+    and what it returned (``I``); run (b) reuses run (a)'s embeddings through a memoising wrapper around the reference's own
+    StreamInferenceDoc (same model, same caches: every line of the reference executes in run (a)).  ~10 minutes of CPU."""
+    import shutil
+    import tempfile
+    import time
+    from oracle import search_ref
+    ref = ref_harness.load_reference()
+    G = ref.driver
+    tmp = tempfile.mkdtemp(prefix="ance_golden_c1_")
+    try:
+        data = os.path.join(tmp, "data")
+        dargs = dict(n_passages=10000, n_train=1000, n_dev=200, L=128, Lq=64, seed=1234, dup_frac=0.01)
+        synth.make_msmarco_like(data, **dargs)
+        wargs = dict(seed=42, n_layers=12, ln_jitter=0.1)
+        sd = encoder_ref.det_state_dict(**wargs)
+        m = ref_harness.build_reference_model("rdot_nll", n_layers=12, seed=0)
+        load_into(m, sd)
+
+        calls = []
+
+        class RecordingIndex(search_ref.OracleIndexFlatIP):
+            def search(self, q, k):
+                D, I = super().search(q, k)
+                calls.append((np.array(q, dtype=np.float32), int(k), D.copy(), I.copy(), self._x))
+                return D, I
+
+        sys.modules["faiss"].IndexFlatIP = RecordingIndex
+        real_stream = G.StreamInferenceDoc
+        memo = {}
+
+        def stream_memo(args, model, fn, prefix, f, is_query_inference=True):
+            if prefix not in memo:
+                memo[prefix] = real_stream(args, model, fn, prefix, f, is_query_inference=is_query_inference)
+            return memo[prefix]
+
+        G.StreamInferenceDoc = stream_memo
+        runs = {}
+        t0 = time.time()
+        for name, jargs, seed, output_num in (
+                ("topk", dict(ann_measure_topk_mrr=True, ann_chunk_factor=1), 0, 0),
+                ("shuffle", dict(ann_measure_topk_mrr=False, ann_chunk_factor=5), 0, 2)):
+            outd = os.path.join(tmp, "out_" + name)
+            full = dict(max_seq_length=128, max_query_length=64, topk_training=200, negative_sample=20, **jargs)
+            res = ref_harness.run_generate_new_ann(data, outd, m, output_num=output_num, checkpoint_path="/x/checkpoint-100/",
+                                                   step=100, seed=seed, **full)
+            with open(os.path.join(outd, "ann_training_data_%d" % output_num)) as f:
+                lines = f.read()
+            with open(os.path.join(outd, "ann_ndcg_%d" % output_num)) as f:
+                nd = json.load(f)
+            runs[name] = dict(args=dict(seed=seed, output_num=output_num, checkpoint_path="/x/checkpoint-100/",
+                                        per_gpu_eval_batch_size=16, **full),
+                              ann_training_data=lines, ann_ndcg=nd, result=[res[0], res[1]])
+        G.StreamInferenceDoc = real_stream
+        sys.modules["faiss"].IndexFlatIP = search_ref.OracleIndexFlatIP
+        # calls: run (a) dev (k = 100), run (a) train (k = 200, all 1,000 queries), run (b) dev, run (b) train chunk
+        (qd, kd, Dd, Id, X), (qt, kt, Dt, It, _) = calls[0], calls[1]
+        assert kd == 100 and kt == 200 and It.shape == (1000, 200) and Id.shape == (200, 100) and X.shape == (10000, 768)
+        assert np.array_equal(calls[2][3], Id) and calls[3][3].shape == (200, 200)
+        # (the chunk's lists come from an sgemm of another shape: BLAS may round its scores differently, so they are stored)
+        np.savez_compressed(os.path.join(OUT, "e2e_config1.npz"), I_train=It.astype(np.uint16), I_dev=Id.astype(np.uint16),
+                            I_train_chunk2=calls[3][3].astype(np.uint16),
+                            D_train64=Dt[:64], D_dev64=Dd[:64], passage_emb16=X[:16], query_emb16=qt[:16], dev_emb16=qd[:16])
+        with open(os.path.join(OUT, "e2e_config1.json"), "w") as f:
+            json.dump(dict(weights=dict(gen="det", checksum=sd_checksum(sd), **wargs), data=dargs, runs=runs,
+                           cpu_seconds=round(time.time() - t0, 1), threads=torch.get_num_threads()), f)
+        return dict(ndcg=runs["topk"]["ann_ndcg"]["ndcg"], lines_topk=runs["topk"]["ann_training_data"].count("\n"),
+                    lines_shuffle=runs["shuffle"]["ann_training_data"].count("\n"), cpu_seconds=round(time.time() - t0, 1))
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
 
@@ -306,6 +396,7 @@ def golden_metrics():
 if __name__ == "__main__":
     torch.set_num_threads(8)
     makers = dict(encoder=golden_encoder, postsearch=golden_postsearch, e2e=golden_end_to_end, e2e_maxp=golden_end_to_end_maxp,
+                  config1=golden_config1,
                   dpr=golden_dpr, preprocess=golden_preprocess, metrics=golden_metrics, dpr_preprocess=golden_dpr_preprocess)
     which = sys.argv[1:] or list(makers)  # `make_golden.py e2e_maxp` regenerates one piece and its manifest entry
     mpath = os.path.join(OUT, "manifest.json")
@@ -313,7 +404,6 @@ if __name__ == "__main__":
     if sys.argv[1:] and os.path.exists(mpath):
         with open(mpath) as f:
             info = json.load(f)
-        assert info.get("torch") == torch.__version__, "partial regeneration needs the torch build of the manifest"
     for name in which:
         info[name] = makers[name]()
     info["torch"], info["numpy"] = torch.__version__, np.__version__

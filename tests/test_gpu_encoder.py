@@ -36,22 +36,7 @@ def _manifest(golden_dir):
         return json.load(f)
 
 
-def _checksum(sd):
-    keys = sorted(sd.keys())
-    return float(sum(sd[k].double().abs().sum().item() for k in keys[:: max(1, len(keys) // 16)]))
-
-
-def _weights(meta, **kw):
-    from oracle import encoder_ref
-    sd = encoder_ref.random_state_dict(seed=meta["seed"], n_layers=meta["n_layers"], ln_jitter=meta["ln_jitter"], **kw)
-    if abs(_checksum(sd) - meta["checksum"]) > 1e-6 * meta["checksum"]:
-        # The golden vectors are the only encoder evidence pinned to the reference's own classes: losing them silently
-        # is not an option.  The same torch build must reproduce the seeded weights; only another build may skip.
-        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "manifest.json")) as f:
-            made_with = json.load(f).get("torch")
-        assert torch.__version__ != made_with, "seeded weights differ from the golden manifest under the torch build that made it"
-        pytest.skip("torch %s draws other random weights than %s, which generated the golden vectors" % (torch.__version__, made_with))
-    return sd
+from golden_util import golden_weights as _weights  # noqa: E402
 
 
 def test_firstp_golden_of_reference(golden_dir):

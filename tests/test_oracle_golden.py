@@ -18,16 +18,7 @@ def _manifest(golden_dir):
         return json.load(f)
 
 
-def _checksum(sd):
-    keys = sorted(sd.keys())
-    return float(sum(sd[k].double().abs().sum().item() for k in keys[:: max(1, len(keys) // 16)]))
-
-
-def _weights(meta, **kw):
-    sd = encoder_ref.random_state_dict(seed=meta["seed"], n_layers=meta["n_layers"], ln_jitter=meta["ln_jitter"], **kw)
-    if abs(_checksum(sd) - meta["checksum"]) > 1e-6 * meta["checksum"]:
-        pytest.skip("torch RNG differs from the one that generated the golden vectors")
-    return sd
+from golden_util import golden_weights as _weights  # noqa: E402
 
 
 def test_encoder_firstp_matches_reference(golden_dir):
@@ -37,6 +28,18 @@ def test_encoder_firstp_matches_reference(golden_dir):
     ids, lens = torch.from_numpy(g["ids"]), g["lens"]
     with torch.no_grad():
         emb = encoder_ref.rdot_nll_ln_emb(sd, ids, encoder_ref.mask_from_lengths(lens, ids.shape[1]), n_layers=2)
+    assert np.abs(emb.numpy() - g["emb"]).max() <= 2e-5
+
+
+def test_encoder_firstp_full_depth_matches_reference(golden_dir):
+    """12 layers: the oracle restatement against RobertaDot_NLL_LN.body_emb itself (model/models.py:149-157) at the depth
+    every headline number is quoted at."""
+    meta = _manifest(golden_dir)["encoder"]["firstp12"]
+    sd = _weights(meta)
+    g = np.load(os.path.join(golden_dir, "encoder_firstp12.npz"))
+    ids, lens = torch.from_numpy(g["ids"]), g["lens"]
+    with torch.no_grad():
+        emb = encoder_ref.rdot_nll_ln_emb(sd, ids, encoder_ref.mask_from_lengths(lens, ids.shape[1]), n_layers=12)
     assert np.abs(emb.numpy() - g["emb"]).max() <= 2e-5
 
 
@@ -170,3 +173,66 @@ def test_end_to_end_maxp_refresh_matches_reference(golden_dir, tmp_path):
     assert abs(ndcg - e["ann_ndcg_0"]["ndcg"]) < 1e-9
     with open(os.path.join(out, "ann_training_data_0")) as f:
         assert f.read() == e["ann_training_data_0"]
+
+
+# ---- BASELINE.json configs[0] at its stated size: tests/golden/e2e_config1.* (the reference's own generate_new_ann on
+# 10,000 passages / 1,000 + 200 queries, 12 layers, top-200, 20 negatives; ~11 minutes of CPU when it was generated) ----
+@pytest.fixture(scope="module")
+def config1(golden_dir, tmp_path_factory):
+    with open(os.path.join(golden_dir, "e2e_config1.json")) as f:
+        e = json.load(f)
+    g = np.load(os.path.join(golden_dir, "e2e_config1.npz"))
+    data = str(tmp_path_factory.mktemp("c1") / "data")
+    synth.make_msmarco_like(data, **e["data"])
+    return e, g, data
+
+
+@pytest.mark.parametrize("run", ["topk", "shuffle"])
+def test_config1_post_search_reproduces_the_reference_files(config1, tmp_path, run):
+    """Given the neighbour lists the reference's index returned, the oracle's restatement of chunking, negative selection
+    (both modes), dev NDCG and the writers reproduces the reference's ann_training_data / ann_ndcg files byte for byte."""
+    e, g, data = config1
+    r = e["runs"][run]
+    a = r["args"]
+    train_pos, dev_pos = ann_ref.load_positive_ids(data)
+    I_dev = g["I_dev"].astype(np.int64)
+    I_all = g["I_train"].astype(np.int64)
+    s, t = ann_ref.query_chunk(1000, a["output_num"], a["ann_chunk_factor"])
+    I = I_all[s:t] if run == "topk" else g["I_train_chunk2"].astype(np.int64)
+    assert I.shape[0] == t - s
+    p2id, q2id = np.arange(e["data"]["n_passages"]), np.arange(1000)[s:t]
+    random.seed(a["seed"])
+    ndcg, n_dev = ann_ref.eval_dev_query(np.arange(200), p2id, dev_pos, I_dev)
+    assert n_dev == r["result"][1] and abs(ndcg - r["ann_ndcg"]["ndcg"]) < 1e-12
+    eff = set(q2id.tolist())
+    neg, _ = ann_ref.generate_negative_passage_ids(q2id, p2id, train_pos, I, eff, a["negative_sample"], a["ann_measure_topk_mrr"])
+    ann_ref.write_ann_files(str(tmp_path), a["output_num"], I, q2id, eff, train_pos, neg, ndcg, a["checkpoint_path"])
+    with open(os.path.join(str(tmp_path), "ann_training_data_%d" % a["output_num"])) as f:
+        assert f.read() == r["ann_training_data"]
+    with open(os.path.join(str(tmp_path), "ann_ndcg_%d" % a["output_num"])) as f:
+        assert json.load(f) == r["ann_ndcg"]
+
+
+def test_config1_embeddings_and_lists_of_the_reference(config1):
+    """The oracle encoder at 12 layers against rows of the reference's own 10,000-passage run, and the stored neighbour
+    lists against the scores those rows imply (first 16 queries x first 16 passages: a spot check that data, weights and
+    fixture belong together; the full fp64 cross-check runs on the GPU, tests/test_gpu_config1.py)."""
+    e, g, data = config1
+    sd = _weights(e["weights"])
+
+    def enc(name, L, n):
+        lens, ids = ann_ref.read_cache(os.path.join(data, name))
+        with torch.no_grad():
+            return encoder_ref.rdot_nll_ln_emb(sd, torch.from_numpy(ids[:n]), encoder_ref.mask_from_lengths(lens[:n], L), n_layers=12).numpy()
+
+    p, q, d = enc("passages", 128, 16), enc("train-query", 64, 16), enc("dev-query", 64, 16)
+    assert np.abs(p - g["passage_emb16"]).max() <= 2e-5
+    assert np.abs(q - g["query_emb16"]).max() <= 2e-5
+    assert np.abs(d - g["dev_emb16"]).max() <= 2e-5
+    # a stored score D[q, r] belongs to passage I[q, r]: check it wherever that passage is one of the 16 encoded here
+    I, D = g["I_train"].astype(np.int64)[:16], g["D_train64"][:16]
+    S = q.astype(np.float64) @ p.astype(np.float64).T
+    hits = [(i, r) for i in range(16) for r in range(200) if I[i, r] < 16]
+    for i, r in hits:
+        assert abs(D[i, r] - S[i, I[i, r]]) <= 2e-2
+    assert np.all(np.diff(g["D_train64"], axis=1) <= 0)  # lists are sorted
