@@ -78,6 +78,9 @@ SYMBOLS = {
     "ance_debug_gemm": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
                                        ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                        ctypes.c_void_p]),
+    "ance_debug_gemm_split": (ctypes.c_int, [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                             ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_float,
+                                             ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
 }
 
 _lib = None
@@ -87,10 +90,11 @@ class AnceLibraryError(RuntimeError):
     pass
 
 
-def build(verbose=False):
+def build(verbose=False, force=False):
     """Compile every HIP source for gfx950 into ance_amd/libance_amd.so (hipcc cross-compiles
-    without a GPU)."""
-    cmd = ["make", "-C", CSRC, "-j8"]
+    without a GPU).  force: rebuild every object (``make -B``) -- the tree ships its .o files to the GPU box, and a
+    "does it build" check must not pass on stale objects."""
+    cmd = ["make", "-C", CSRC, "-j8"] + (["-B"] if force else [])
     res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if verbose or res.returncode != 0:
         print(res.stdout)

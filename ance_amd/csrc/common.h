@@ -54,6 +54,17 @@ __host__ __device__ inline u64 pack_key(float s, uint32_t row) {
 __host__ __device__ inline float key_score(u64 k) { return unorder_f32((uint32_t)(k >> 32)); }
 __host__ __device__ inline uint32_t key_row(u64 k) { return 0xFFFFFFFFu - (uint32_t)(k & 0xFFFFFFFFull); }
 
+// fp32 x4 -> fp16 x4 (round to nearest even) with the result PINNED in its registers.  An (hi, lo) pair is only as good as the
+// agreement between the hi that is stored and the hi that  lo = fp16(v - hi)  was formed from.  Without the barrier hipcc is
+// free to convert v twice -- a packed conversion feeding the 8-byte store and a scalar one feeding the subtraction -- and on
+// gfx950 the two disagree on exact ties: the stored pair is then off by one fp16 ulp of v (found by tests/test_gpu_gemm.py::
+// test_split_gemm_pair_epilogues on 43 of 1.5 M GELU outputs; it cost the split mode a factor 10 of its accuracy).
+__device__ __forceinline__ f16x4 cvt_f16x4_pinned(const f32x4 v) {
+    f16x4 h = f16x4{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+    asm volatile("" : "+v"(h));
+    return h;
+}
+
 __device__ inline int lane_id() { return (int)(threadIdx.x & 63); }
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }

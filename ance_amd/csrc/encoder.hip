@@ -355,7 +355,7 @@ __global__ void __launch_bounds__(256) head_kernel(const float *pre, const _Floa
 
 // ---- folded-LayerNorm path ---------------------------------------------------------------------
 __device__ __forceinline__ void split_store(const f32x4 v, _Float16 *hi, _Float16 *lo, int c4) {
-    const f16x4 h = f16x4{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+    const f16x4 h = cvt_f16x4_pinned(v);
     const f16x4 r = f16x4{(_Float16)(v[0] - (float)h[0]), (_Float16)(v[1] - (float)h[1]), (_Float16)(v[2] - (float)h[2]),
                           (_Float16)(v[3] - (float)h[3])};
     reinterpret_cast<f16x4 *>(hi)[c4] = h;
@@ -459,7 +459,7 @@ constexpr float SPLIT_SCALE_H = 2048.0f, SPLIT_INV_H = 1.0f / 2048.0f;
 constexpr int HP = 2 * H;  // halves per pair row of a 768-wide stream: [hi (768) | lo' (768)]
 
 __device__ __forceinline__ void split_store_scaled(const f32x4 v, _Float16 *row, int width, int c4) {
-    const f16x4 h = f16x4{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+    const f16x4 h = cvt_f16x4_pinned(v);
     const f16x4 r = f16x4{(_Float16)((v[0] - (float)h[0]) * SPLIT_SCALE_H), (_Float16)((v[1] - (float)h[1]) * SPLIT_SCALE_H),
                           (_Float16)((v[2] - (float)h[2]) * SPLIT_SCALE_H), (_Float16)((v[3] - (float)h[3]) * SPLIT_SCALE_H)};
     reinterpret_cast<f16x4 *>(row)[c4] = h;

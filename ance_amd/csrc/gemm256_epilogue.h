@@ -268,7 +268,7 @@ __device__ __forceinline__ void gemm256_epilogue(const GemmArgs &G, f32x16 (&acc
                     const float b0 = __builtin_fmaf(-mean[it], a, bias_beta[e]);
                     v[e] += __builtin_fmaf((float)rh[it][e], a, __builtin_fmaf((float)rl[it][e], a, b0));
                 }
-                const f16x4 hi = f16x4{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+                const f16x4 hi = cvt_f16x4_pinned(v);
                 const f16x4 lo = f16x4{(_Float16)(v[0] - (float)hi[0]), (_Float16)(v[1] - (float)hi[1]),
                                        (_Float16)(v[2] - (float)hi[2]), (_Float16)(v[3] - (float)hi[3])};
                 *reinterpret_cast<f16x4 *>(ph + it * rstep) = hi;
@@ -379,12 +379,19 @@ __device__ __forceinline__ void gemm256_epilogue(const GemmArgs &G, f32x16 (&acc
 
 // ---- epilogues of the SPLIT (fp32-grade) GEMM ---------------------------------------------------------------------------
 // exact-erf GELU (the reference's: transformers "gelu" = x Phi(x), erf form), full-precision device erff
-__device__ __forceinline__ float gelu_exact(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// (contraction off here and in the split epilogue: hipcc contracts a * b + c into an fma in SOME of the unrolled instances of
+// a loop and not in others, so a row's last bit would depend on which pass / register slot of the tile it lands in -- and with
+// it on the micro-batch split and the number of GPUs.  Every fused operation below is written out as fmaf.)
+__device__ __forceinline__ float gelu_exact(float x) {
+#pragma clang fp contract(off)
+    return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
 
 // v -> (hi, lo'): hi = fp16(v), lo' = fp16((v - hi) 2^11).  v - hi is exact in fp32; the scale keeps lo' in the fp16 normal range
 constexpr float SPLIT_SCALE = 2048.0f, SPLIT_INV = 1.0f / 2048.0f;
 __device__ __forceinline__ void split4(const f32x4 v, f16x4 *hi, f16x4 *lo) {
-    const f16x4 h = f16x4{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+#pragma clang fp contract(off)
+    const f16x4 h = cvt_f16x4_pinned(v);
     *hi = h;
     *lo = f16x4{(_Float16)((v[0] - (float)h[0]) * SPLIT_SCALE), (_Float16)((v[1] - (float)h[1]) * SPLIT_SCALE),
                 (_Float16)((v[2] - (float)h[2]) * SPLIT_SCALE), (_Float16)((v[3] - (float)h[3]) * SPLIT_SCALE)};
@@ -399,6 +406,7 @@ __device__ __forceinline__ void split4(const f32x4 v, f16x4 *hi, f16x4 *lo) {
 template <int EPI>
 __device__ __forceinline__ void gemm256_epilogue_split(const GemmArgs &G, f32x16 (&acc)[2][4], float *smem_f, int m0, int n0,
                                                        int w, int l) {
+#pragma clang fp contract(off)
     const int g = l >> 5, i = l & 31;
     const int wm = w >> 2, wn = w & 3;
     const int mw0 = m0 + wm * 128, nw0 = n0 + wn * 64;

@@ -481,3 +481,29 @@ extern "C" int ance_debug_gemm(int ablate, int epi, const void *d_a_f16, const v
     int rc = launch_gemm_f16(epi, G, (hipStream_t)stream);
     return rc ? rc : check_launch("ance_debug_gemm");
 }
+
+// Test hook (include/ance_amd.h): the SPLIT GEMM with each of its three epilogues on caller-provided pair operands.
+extern "C" int ance_debug_gemm_split(int epi, const void *d_a_pair, const void *d_b_pair, int M, int N, int K, const float *d_bias,
+                                     const float *d_vec1, const float *d_vec2, const float *d_part, float ln_eps,
+                                     const void *d_res_pair, void *d_out, float *d_part_out, void *stream) {
+    using namespace ance;
+    if (!d_a_pair || !d_b_pair || !d_bias || !d_vec1 || !d_part || !d_out || epi < EPI_S_QKV || epi > EPI_S_RESLN ||
+        (epi == EPI_S_RESLN && (!d_vec2 || !d_res_pair || !d_part_out || N != 768))) {
+        set_last_error("ance_debug_gemm_split: invalid argument");
+        return ANCE_E_INVALID;
+    }
+    GemmArgs G;
+    memset(&G, 0, sizeof(G));
+    G.A = (const _Float16 *)d_a_pair; G.lda = 2 * K; G.B = (const _Float16 *)d_b_pair; G.ldb = 2 * K;
+    G.M = M; G.N = N; G.K = K; G.bias = d_bias; G.part_in = d_part; G.ln_eps = ln_eps;
+    if (epi == EPI_S_QKV) {
+        G.csum = d_vec1; G.out32 = (float *)d_out; G.ldc = N;
+    } else if (epi == EPI_S_GELU) {
+        G.csum = d_vec1; G.out16 = (_Float16 *)d_out; G.ldc = 2 * N;
+    } else {
+        G.res_gamma = d_vec1; G.res_beta = d_vec2; G.res_hi = (const _Float16 *)d_res_pair; G.ldr = 2 * N;
+        G.out16 = (_Float16 *)d_out; G.ldc = 2 * N; G.part_out = d_part_out;
+    }
+    int rc = launch_gemm_f16(epi, G, (hipStream_t)stream);
+    return rc ? rc : check_launch("ance_debug_gemm_split");
+}

@@ -238,13 +238,11 @@ __global__ void __launch_bounds__(256) attention32_kernel(const float *qkv, floa
                 _Float16 *ph = ctx_pair + orow * 1536 + h * 64;
 #pragma unroll
                 for (int d = 0; d < 64; d += 4) {
-                    f16x4 hi, lo;
+                    const f32x4 v = {acc[d] * inv, acc[d + 1] * inv, acc[d + 2] * inv, acc[d + 3] * inv};
+                    const f16x4 hi = cvt_f16x4_pinned(v);  // the stored hi and the hi of (v - hi) must be the same bits
+                    f16x4 lo;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float v = acc[d + e] * inv;
-                        hi[e] = (_Float16)v;
-                        lo[e] = (_Float16)((v - (float)hi[e]) * 2048.0f);
-                    }
+                    for (int e = 0; e < 4; ++e) lo[e] = (_Float16)((v[e] - (float)hi[e]) * 2048.0f);
                     *reinterpret_cast<f16x4 *>(ph + d) = hi;
                     *reinterpret_cast<f16x4 *>(ph + 768 + d) = lo;
                 }

@@ -245,6 +245,18 @@ int ance_encode_ids(AnceEncoder *enc, const int32_t *d_ids, int64_t ld_ids, cons
 int ance_debug_gemm(int ablate, int epi, const void *d_a_f16, const void *d_b_f16, int M, int N, int K,
                     const float *d_bias, void *d_out, const float *d_res32, void *stream);
 
+/* Test hook: the SPLIT (fp32-grade) GEMM of the encoder with one of its epilogues.  acc[m][n] = sum_k a[m][k] b[n][k] with
+ * a = a_hi + a_lo' 2^-11 (b likewise); d_a_pair [M, 2K] / d_b_pair [N, 2K] fp16 rows [hi (K) | lo' (K)]; (mu_m, r_m) = mean and
+ * 1 / sqrt(var + ln_eps) of row m combined from d_part [M][12][2], the (mean, M2) of its twelve 64-column slices.
+ *   epi 8   d_out fp32 [M, N]      = r_m (acc - mu_m vec1[n]) + bias[n]                             (vec1 = csum)
+ *   epi 9   d_out fp16 pair [M, 2N] = split(gelu_erf(r_m (acc - mu_m vec1[n]) + bias[n]))
+ *   epi 10  d_out fp16 pair [M, 2N] = split(acc + bias[n] + (res[m][n] - mu_m) r_m vec1[n] + vec2[n])   (vec1 = gamma, vec2 = beta,
+ *           res = d_res_pair [M, 2N] pair rows; N = 768), d_part_out [M][12][2] = slice statistics of the output rows
+ * M, N multiples of 256, K of 64, >= 128. */
+int ance_debug_gemm_split(int epi, const void *d_a_pair, const void *d_b_pair, int M, int N, int K, const float *d_bias,
+                          const float *d_vec1, const float *d_vec2, const float *d_part, float ln_eps, const void *d_res_pair,
+                          void *d_out, float *d_part_out, void *stream);
+
 /* Re-reads every ANCE_* tuning knob from the environment (they are otherwise read once per process).  For tests and
  * sweeps that change a knob between two calls; not thread-safe against concurrent searches. */
 void ance_reload_env(void);

@@ -167,3 +167,74 @@ void ance_oracle_topk_merge(const float *Dp, const int64_t *Ip, int n_parts, int
     }
     free(buf);
 }
+
+/* ---- the algorithm of faiss-cpu's IndexFlatIP.search, for the timed CPU baseline (bench.py cpu_baseline, kind "port") ----
+ * faiss computes blocks of the score matrix with sgemm (4,096 queries x 1,024 database rows, faiss/utils/distances.cpp:
+ * distance_compute_blas_query_bs / _database_bs) and feeds every block row into a per-query k-heap (HeapResultHandler),
+ * queries in parallel under OpenMP.  The sgemm is NumPy's BLAS (oracle/search_ref.py); this is the heap side: one size-k
+ * min-heap per query under the canonical order, updated from a score block S[nq][nb] whose column j is row row_base + j.
+ * heap_s / heap_i: [nq][k], heap_cnt: [nq] (0 before the first block). */
+void ance_oracle_heap_update(const float *S, int64_t nq, int64_t nb, int64_t ld, int64_t row_base, int k, float *heap_s,
+                             int64_t *heap_i, int32_t *heap_cnt)
+{
+#pragma omp parallel for schedule(static)
+    for (int64_t qi = 0; qi < nq; ++qi) {
+        const float *row = S + (size_t)qi * ld;
+        float *hs = heap_s + (size_t)qi * k;
+        int64_t *hi = heap_i + (size_t)qi * k;
+        int cnt = heap_cnt[qi];
+        for (int64_t j = 0; j < nb; ++j) {
+            const float s = row[j];
+            const int64_t id = row_base + j;
+            if (cnt < k) {
+                if (s != s) continue;
+                hs[cnt] = s; hi[cnt] = id; ++cnt;
+                if (cnt == k) {  /* heapify: root = the worst kept entry */
+                    for (int p0 = k / 2 - 1; p0 >= 0; --p0) {
+                        int p = p0;
+                        for (;;) {
+                            int l = 2 * p + 1, r = l + 1, w = p;
+                            if (l < k && beats(hs[w], hi[w], hs[l], hi[l])) w = l;
+                            if (r < k && beats(hs[w], hi[w], hs[r], hi[r])) w = r;
+                            if (w == p) break;
+                            float ts = hs[p]; hs[p] = hs[w]; hs[w] = ts;
+                            int64_t ti = hi[p]; hi[p] = hi[w]; hi[w] = ti;
+                            p = w;
+                        }
+                    }
+                }
+            } else if (s > hs[0] || (s == hs[0] && id < hi[0])) {
+                hs[0] = s; hi[0] = id;
+                int p = 0;
+                for (;;) {
+                    int l = 2 * p + 1, r = l + 1, w = p;
+                    if (l < k && beats(hs[w], hi[w], hs[l], hi[l])) w = l;
+                    if (r < k && beats(hs[w], hi[w], hs[r], hi[r])) w = r;
+                    if (w == p) break;
+                    float ts = hs[p]; hs[p] = hs[w]; hs[w] = ts;
+                    int64_t ti = hi[p]; hi[p] = hi[w]; hi[w] = ti;
+                    p = w;
+                }
+            }
+        }
+        heap_cnt[qi] = cnt;
+    }
+}
+
+/* heaps -> sorted lists (score desc, id asc), padded with (-FLT_MAX, -1) */
+void ance_oracle_heap_finish(int64_t nq, int k, const float *heap_s, const int64_t *heap_i, const int32_t *heap_cnt, float *D,
+                             int64_t *I)
+{
+#pragma omp parallel for schedule(static)
+    for (int64_t qi = 0; qi < nq; ++qi) {
+        ent_t *buf = (ent_t *)malloc(sizeof(ent_t) * (size_t)(k > 0 ? k : 1));
+        const int cnt = heap_cnt[qi];
+        for (int r = 0; r < cnt; ++r) { buf[r].s = heap_s[(size_t)qi * k + r]; buf[r].i = heap_i[(size_t)qi * k + r]; }
+        qsort(buf, (size_t)cnt, sizeof(ent_t), cmp_rank);
+        for (int r = 0; r < k; ++r) {
+            if (r < cnt) { D[(size_t)qi * k + r] = buf[r].s; I[(size_t)qi * k + r] = buf[r].i; }
+            else { D[(size_t)qi * k + r] = -FLT_MAX; I[(size_t)qi * k + r] = -1; }
+        }
+        free(buf);
+    }
+}

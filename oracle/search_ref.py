@@ -42,7 +42,12 @@ def lib():
                                           ctypes.c_int, ctypes.c_int, f32p, i64p]
         L.ance_oracle_topk_row.argtypes = [f32p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int, f32p, i64p]
         L.ance_oracle_topk_merge.argtypes = [f32p, i64p, ctypes.c_int, ctypes.c_int64, ctypes.c_int, f32p, i64p]
-        for fn in (L.ance_oracle_ip_scores, L.ance_oracle_ip_topk, L.ance_oracle_topk_row, L.ance_oracle_topk_merge):
+        i32p = ctypes.POINTER(ctypes.c_int32)
+        L.ance_oracle_heap_update.argtypes = [f32p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int,
+                                              f32p, i64p, i32p]
+        L.ance_oracle_heap_finish.argtypes = [ctypes.c_int64, ctypes.c_int, f32p, i64p, i32p, f32p, i64p]
+        for fn in (L.ance_oracle_ip_scores, L.ance_oracle_ip_topk, L.ance_oracle_topk_row, L.ance_oracle_topk_merge,
+                   L.ance_oracle_heap_update, L.ance_oracle_heap_finish):
             fn.restype = None
         _LIB = L
     return _LIB
@@ -127,6 +132,37 @@ def flat_ip_topk_blas(x, q, k, row_base=0, q_block=1024, x_block=262144):
         else:
             d_, i_ = topk_merge(np.stack(partD), np.stack(partI), k)
             D[q0:q0 + q_block], I[q0:q0 + q_block] = d_, i_
+    return D, I
+
+
+def flat_ip_topk_faisslike(x, q, k, row_base=0, q_block=4096, x_block=8192):
+    """faiss-cpu IndexFlatIP.search as faiss runs it: blocks of the score matrix by BLAS sgemm (4,096 queries per block,
+    faiss/utils/distances.cpp) streamed into one k-heap per query, queries in parallel under OpenMP (ip_topk_ref.c:
+    ance_oracle_heap_update).  Same results as ``flat_ip_topk_blas`` up to BLAS rounding of a score by block shape; this is
+    the form timed as the CPU baseline (selection by ``np.partition`` per row is several times slower than a heap)."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    q = np.ascontiguousarray(q, dtype=np.float32)
+    n, nq = x.shape[0], q.shape[0]
+    D = np.empty((nq, k), dtype=np.float32)
+    I = np.empty((nq, k), dtype=np.int64)
+    L = lib()
+    f32p, i64p, i32p = ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int32)
+    for q0 in range(0, nq, q_block):
+        qb = q[q0:q0 + q_block]
+        m = qb.shape[0]
+        hs = np.empty((m, k), dtype=np.float32)
+        hi = np.empty((m, k), dtype=np.int64)
+        hc = np.zeros(m, dtype=np.int32)
+        S = np.empty((m, min(x_block, max(n, 1))), dtype=np.float32)
+        for x0 in range(0, n, x_block):
+            xb = x[x0:x0 + x_block]
+            Sb = S[:, :xb.shape[0]]
+            np.matmul(qb, xb.T, out=Sb)
+            L.ance_oracle_heap_update(Sb.ctypes.data_as(f32p), m, xb.shape[0], S.shape[1], row_base + x0, k,
+                                      hs.ctypes.data_as(f32p), hi.ctypes.data_as(i64p), hc.ctypes.data_as(i32p))
+        Db, Ib = D[q0:q0 + m], I[q0:q0 + m]
+        L.ance_oracle_heap_finish(m, k, hs.ctypes.data_as(f32p), hi.ctypes.data_as(i64p), hc.ctypes.data_as(i32p),
+                                  Db.ctypes.data_as(f32p), Ib.ctypes.data_as(i64p))
     return D, I
 
 

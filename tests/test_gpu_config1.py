@@ -84,25 +84,38 @@ def c1(golden_dir, tmp_path_factory):
                                  S_dev=S_dev, train_pos=train_pos, dev_pos=dev_pos)
 
 
-def tau_violation(s, X, tau, excluded=()):
-    """0.0 if list X is an exact ranking of some scores within tau of s (see module docstring), else the worst excess."""
+def tau_needed(s, X, excluded=()):
+    """The smallest tau for which list X is an exact ranking of SOME scores within tau of s (see module docstring):
+    half of the largest inversion -- a later entry above an earlier one, or an admissible row left out above the weakest kept."""
     X = np.asarray(X, dtype=np.int64)
     if len(X) == 0:
         return 0.0
     sx = s[X]
     worst = 0.0
-    # order: every later entry may exceed an earlier one by at most 2 tau
     suffix_max = np.maximum.accumulate(sx[::-1])[::-1]
     if len(X) > 1:
-        worst = max(worst, float((suffix_max[1:] - sx[:-1]).max()) - 2 * tau)
-    # completeness: nothing admissible that was left out may beat the weakest entry by more than 2 tau
+        worst = max(worst, float((suffix_max[1:] - sx[:-1]).max()))
     mask = np.ones(len(s), dtype=bool)
     mask[X] = False
     if len(excluded):
         mask[np.asarray(list(excluded), dtype=np.int64)] = False
     if mask.any():
-        worst = max(worst, float(s[mask].max() - sx.min()) - 2 * tau)
-    return max(worst, 0.0)
+        worst = max(worst, float(s[mask].max() - sx.min()))
+    return max(worst, 0.0) / 2.0
+
+
+def tau_violation(s, X, tau, excluded=()):
+    """0.0 if list X is consistent with the fp64 scores s under score errors <= tau, else by how much tau falls short."""
+    return max(tau_needed(s, X, excluded) - tau, 0.0)
+
+
+def chain_score_error(p, q, S64):
+    """max |fp32 score the search ranks by - fp64 truth| over ALL pairs: the search's scores are fp32 fmaf chains over k
+    (csrc/ip_topk*.hip, bit-identical to oracle/ip_topk_ref.c: tests/test_gpu_search.py), at |score| ~ 740 one fp32 ulp is
+    6e-5 -- part of tau_G together with the embeddings' own error."""
+    from oracle import search_ref
+    S = search_ref.ip_scores_chain(p.cpu().numpy(), q.cpu().numpy())
+    return float(np.abs(S.astype(np.float64) - S64).max())
 
 
 def test_reference_lists_are_consistent_with_fp64_truth(c1):
@@ -118,13 +131,14 @@ def test_reference_lists_are_consistent_with_fp64_truth(c1):
     tau_R = max(float(np.abs(g["D_train64"] - np.take_along_axis(c1.S_train[:64], I_train[:64], 1)).max()),
                 float(np.abs(g["D_dev64"] - np.take_along_axis(c1.S_dev[:64], I_dev[:64], 1)).max()))
     assert tau_R <= 5e-3, tau_R
-    tau = 2.0 * tau_R  # margin: tau_R is the maximum over 19,200 of the reference's 10^7 scores
-    bad = [q for q in range(1000) if tau_violation(c1.S_train[q], I_train[q], tau) > 0]
-    bad_dev = [q for q in range(200) if tau_violation(c1.S_dev[q], I_dev[q], tau) > 0]
-    _record("reference_vs_fp64", dict(emb_max_abs=emb_err, tau_R=tau_R, train_lists_inconsistent=len(bad),
-                                      dev_lists_inconsistent=len(bad_dev)))
-    assert not bad and not bad_dev, (bad[:5], bad_dev[:5])
-    c1.tau_R = tau
+    # tau_R is the maximum over 19,200 of the reference's 10^7 scores: the bound used for its lists is 4 x that, and what
+    # its lists actually need is recorded
+    need = max(tau_needed(c1.S_train[q], I_train[q]) for q in range(1000))
+    need_dev = max(tau_needed(c1.S_dev[q], I_dev[q]) for q in range(200))
+    _record("reference_vs_fp64", dict(emb_max_abs=emb_err, tau_R_sampled=tau_R, tau_needed_by_train_lists=need,
+                                      tau_needed_by_dev_lists=need_dev))
+    assert need <= 4.0 * tau_R and need_dev <= 4.0 * tau_R, (need, need_dev, tau_R)
+    c1.tau_R = 4.0 * tau_R
 
 
 def _run_job(c1, mode_env, run_name, tmp_path, monkeypatch):
@@ -192,14 +206,11 @@ def test_topk_mode_job_against_the_reference_run(c1, mode, tmp_path, monkeypatch
     ref = c1.e["runs"]["topk"]
     # our scores against the truth: tau_G over ALL 10^7 (query, passage) pairs
     emb_err = float(max((p.double() - c1.p64).abs().max(), (tq.double() - c1.q64).abs().max(), (dq.double() - c1.d64).abs().max()))
-    S_ours = (tq.double() @ p.double().T).cpu().numpy()
-    S_ours_dev = (dq.double() @ p.double().T).cpu().numpy()
-    tau_G = 1.0001 * max(float(np.abs(S_ours - c1.S_train).max()), float(np.abs(S_ours_dev - c1.S_dev).max()))
-    del S_ours, S_ours_dev
+    tau_G = 1.0001 * max(chain_score_error(p, tq, c1.S_train), chain_score_error(p, dq, c1.S_dev))
 
     ref_lines, got_lines = _lines(ref["ann_training_data"]), _lines(text)
     assert set(ref_lines) == set(got_lines) and len(got_lines) == 1000
-    differing, unexplained = [], []
+    differing, unexplained, need_g, need_r = [], [], 0.0, 0.0
     for q in ref_lines:
         if ref_lines[q] == got_lines[q]:
             continue
@@ -207,7 +218,9 @@ def test_topk_mode_job_against_the_reference_run(c1, mode, tmp_path, monkeypatch
         (pos_r, neg_r), (pos_g, neg_g) = _negs(ref_lines[q]), _negs(got_lines[q])
         assert pos_r == pos_g and len(neg_g) == len(neg_r) == NEG
         s = c1.S_train[int(q)]
-        if tau_violation(s, neg_g, tau_G, excluded=[pos_g]) > 0 or tau_violation(s, neg_r, c1.tau_R, excluded=[pos_r]) > 0:
+        ng, nr = tau_needed(s, neg_g, excluded=[pos_g]), tau_needed(s, neg_r, excluded=[pos_r])
+        need_g, need_r = max(need_g, ng), max(need_r, nr)
+        if ng > tau_G or nr > c1.tau_R:
             unexplained.append(int(q))
     same_sets = sum(set(_negs(ref_lines[q])[1]) == set(_negs(got_lines[q])[1]) for q in ref_lines)
 
@@ -223,17 +236,18 @@ def test_topk_mode_job_against_the_reference_run(c1, mode, tmp_path, monkeypatch
     _record("topk_" + mode, dict(lines=1000, identical_lines=1000 - len(differing), identical_negative_sets=same_sets,
                                  differing_lines_explained_by_near_ties=len(differing) - len(unexplained),
                                  unexplained=unexplained[:20], emb_max_abs_vs_fp64=emb_err, tau_G=tau_G, tau_R=c1.tau_R,
+                                 tau_needed_by_our_differing_lists=need_g, tau_needed_by_reference_differing_lists=need_r,
                                  ndcg=nd["ndcg"], ndcg_reference=ref["ann_ndcg"]["ndcg"], abs_delta_ndcg=d_ndcg,
                                  dev_lists_consistent=dev_explained))
     assert not unexplained, unexplained[:10]
     assert dev_explained
     if mode == "fp32":
         assert emb_err <= 2e-5, emb_err          # stated fp32-mode tolerance
-        assert len(differing) <= 100, len(differing)  # two fp32 implementations: near-ties only, and few of them
+        assert len(differing) <= 120, len(differing)  # two fp32 implementations: near-ties only, and few of them
         assert d_ndcg <= 5e-3
     elif mode == "split":
-        assert emb_err <= 4e-5, emb_err
-        assert len(differing) <= 150, len(differing)
+        assert emb_err <= 2e-5, emb_err          # stated split-mode tolerance
+        assert len(differing) <= 120, len(differing)
         assert d_ndcg <= 5e-3
     else:
         assert emb_err <= 5e-3, emb_err          # stated default-mode tolerance
@@ -253,8 +267,7 @@ def test_shuffle_mode_job_against_the_reference_run(c1, mode, tmp_path, monkeypa
         c1.tau_R = 1e-2
     a, text, nd, dq, p, tq = _run_job(c1, MODES[mode], "shuffle", tmp_path, monkeypatch)
     ref = c1.e["runs"]["shuffle"]
-    S_ours = (tq[400:600].double() @ p.double().T).cpu().numpy()
-    tau_G = 1.0001 * float(np.abs(S_ours - c1.S_train[400:600]).max())
+    tau_G = 1.0001 * chain_score_error(p, tq[400:600], c1.S_train[400:600])
     _, I = search_ref.flat_ip_topk_chain(p.cpu().numpy(), tq[400:600].cpu().numpy(), K_TRAIN)
     assert all(tau_violation(c1.S_train[400 + j], I[j], tau_G) == 0 for j in range(200))
     out2 = str(tmp_path / "oracle_out")

@@ -67,3 +67,102 @@ def test_full_chip_shape_repeated(epi):
         bad = err > tol
         assert not bad.any(), "epi %d rep %d: %d bad, max err %.4g at %s" % (
             epi, rep, int(bad.sum()), float(err.max()), torch.nonzero(bad)[:3].tolist())
+
+
+def _pair(v):
+    hi = v.half()
+    lo = ((v - hi.float()) * 2048.0).half()
+    return hi, lo
+
+
+def _unpair(p, n):
+    return p[:, :n].double() + p[:, n:].double() / 2048.0
+
+
+def _run_split(epi, M, N, K, seed=0, zero_a_lo=False, zero_b_lo=False):
+    """The split GEMM (three fp16 MFMA passes over pair operands) through its test hook with one of its three epilogues,
+    against the same expression in fp64.  Returns (got, ref, scale): scale = the magnitude rounding errors are relative to."""
+    from ance_amd import _lib
+    L = _lib.lib()
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    a = torch.randn((M, K), generator=g, device="cuda")
+    b = torch.randn((N, K), generator=g, device="cuda") * 0.02
+    ah, al = _pair(a)
+    bh, bl = _pair(b)
+    if zero_a_lo:
+        al.zero_()
+    if zero_b_lo:
+        bl.zero_()
+    ap = torch.cat([ah, al], dim=1).contiguous()
+    bp = torch.cat([bh, bl], dim=1).contiguous()
+    bias = torch.randn(N, generator=g, device="cuda")
+    vec1 = torch.randn(N, generator=g, device="cuda")
+    vec2 = torch.randn(N, generator=g, device="cuda")
+    # slice statistics: mean m_j per 64-column slice, M2 = 64 s^2 -> row mean mu, variance s^2 + var(m_j)
+    part = torch.empty((M, 12, 2), device="cuda")
+    part[:, :, 0] = torch.randn((M, 12), generator=g, device="cuda") * 0.1
+    part[:, :, 1] = 64.0 * (0.5 + torch.rand((M, 12), generator=g, device="cuda"))
+    eps = 1e-5
+    res = torch.randn((M, N), generator=g, device="cuda")
+    rp = torch.cat(_pair(res), dim=1).contiguous()
+    out = torch.empty((M, N), dtype=torch.float32, device="cuda") if epi == 8 else torch.zeros((M, 2 * N), dtype=torch.float16, device="cuda")
+    part_out = torch.zeros((M, N // 64, 2), device="cuda")
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    rc = L.ance_debug_gemm_split(epi, P(ap), P(bp), M, N, K, P(bias), P(vec1), P(vec2), P(part), eps, P(rp), P(out), P(part_out),
+                                 _lib.current_stream_ptr())
+    _lib.check(rc, "ance_debug_gemm_split")
+    A = ah.double() + al.double() / 2048.0
+    B = bh.double() + bl.double() / 2048.0
+    acc = A @ B.t()
+    dropped = ((al.double() / 2048.0).abs() @ (bl.double() / 2048.0).abs().t())  # the lo x lo term the kernel leaves out
+    m = part[:, :, 0].double()
+    mu = m.mean(1)
+    var = (part[:, :, 1].double() + 64.0 * (m - mu[:, None]) ** 2).sum(1) / 768.0
+    r = 1.0 / torch.sqrt(var + eps)
+    mag = A.abs() @ B.abs().t()
+    if epi in (8, 9):
+        ref = r[:, None] * (acc - mu[:, None] * vec1.double()[None, :]) + bias.double()[None, :]
+        scale = (mag + dropped + (mu[:, None] * vec1.double()[None, :]).abs()) * r[:, None] + bias.double().abs()[None, :]
+        if epi == 9:
+            ref = torch.nn.functional.gelu(ref)
+            scale = scale + ref.abs()
+        got = out.double() if epi == 8 else _unpair(out, N)
+        return got, ref, scale, None, None
+    R = _unpair(rp, N)
+    ln = (R - mu[:, None]) * r[:, None] * vec1.double()[None, :] + vec2.double()[None, :]
+    ref = acc + bias.double()[None, :] + ln
+    scale = mag + dropped + bias.double().abs()[None, :] + ((R.abs() + mu.abs()[:, None]) * r[:, None] * vec1.double().abs()[None, :]) + \
+        vec2.double().abs()[None, :]
+    s = ref.reshape(M, N // 64, 64)
+    want_part = torch.stack([s.mean(-1), ((s - s.mean(-1, keepdim=True)) ** 2).sum(-1)], dim=-1)
+    return _unpair(out, N), ref, scale, part_out.double(), want_part
+
+
+@pytest.mark.parametrize("shape", [(256, 256, 128), (512, 2304, 768), (768, 768, 3072), (1024, 3072, 768)])
+@pytest.mark.parametrize("variant", ["full", "a_lo_zero", "b_lo_zero", "both_lo_zero"])
+def test_split_gemm_is_fp32_grade(shape, variant):
+    """|error| relative to the magnitudes summed: every partial product is exact in fp32 (11 x 11 bits), so what is left is
+    fp32 accumulation (measured unbiased, std 1.4 ulp at K = 768: scripts/mfma_rounding_probe.py) and the dropped lo x lo term
+    (2^-22, part of the scale).  The variants zero one or both lo halves: a wrong K-tile of one correction segment would show
+    up in exactly one of them."""
+    M, N, K = shape
+    got, ref, scale, _, _ = _run_split(8, M, N, K, seed=7, zero_a_lo=variant in ("a_lo_zero", "both_lo_zero"),
+                                       zero_b_lo=variant in ("b_lo_zero", "both_lo_zero"))
+    rel = (got - ref).abs() / scale
+    assert float(rel.max()) <= 5e-7, (variant, shape, float(rel.max()), torch.nonzero(rel > 5e-7)[:3].tolist())
+
+
+@pytest.mark.parametrize("epi,shape", [(9, (512, 3072, 768)), (9, (256, 256, 128)), (10, (512, 768, 768)), (10, (768, 768, 3072)),
+                                       (10, (256, 768, 128))])
+def test_split_gemm_pair_epilogues(epi, shape):
+    """The two pair-writing epilogues on EVERY row and column of several tiles: exact-erf GELU -> (hi, lo') pair (epi 9) and
+    bias + LayerNorm(residual pair) -> pair + slice statistics (epi 10).  A pair carries 22 bits: 2^-22 of the value on top of
+    the GEMM's own 5e-7."""
+    M, N, K = shape
+    got, ref, scale, part, want_part = _run_split(epi, M, N, K, seed=11)
+    rel = (got - ref).abs() / scale
+    assert float(rel.max()) <= 1e-6, (epi, shape, float(rel.max()), torch.nonzero(rel > 1e-6)[:5].tolist())
+    if part is not None:
+        dm = (part[..., 0] - want_part[..., 0]).abs()
+        dq = (part[..., 1] - want_part[..., 1]).abs() / want_part[..., 1]
+        assert float(dm.max()) <= 2e-6 and float(dq.max()) <= 2e-5, (float(dm.max()), float(dq.max()), torch.nonzero(dq > 2e-5)[:5].tolist())
