@@ -302,7 +302,8 @@ def generate_new_ann(args, output_num, checkpoint_path, training_query_positive_
     if model is None:
         from .encoder import load_model
         model = load_model(args.model_type, checkpoint_path, max_seq_length=args.max_seq_length,
-                           max_tokens=getattr(args, "max_tokens", 65536), device=getattr(args, "device", None))
+                           max_tokens=getattr(args, "max_tokens", 65536), device=getattr(args, "device", None),
+                           precision=getattr(args, "encoder_precision", None))
     chunks = getattr(model, "chunks", 1)
     ph.mark("load_model")
 
@@ -450,6 +451,9 @@ def get_arguments(argv=None):
     # additions (not in the reference)
     p.add_argument("--max_tokens", default=65536, type=int, help="tokens per encoder micro-batch")
     p.add_argument("--seed", default=None, type=int, help="seed `random` before negative sampling")
+    p.add_argument("--encoder_precision", default=None, choices=["fp16", "split", "fp32"],
+                   help="encoder arithmetic: fp16 = fp16 MFMA operands (default, 3e-3 on the embeddings); split = fp16-pair operands, "
+                        "fp32-grade like the reference's own fp32 forward (2e-5, ~2.6 x slower); fp32 = fp32 operands (audit path)")
     return p.parse_args(argv)
 
 

@@ -58,10 +58,31 @@ def count_layers(state_dict, prefix):
 class Encoder:
     """One transformer tower + (optional) ANCE head resident in HBM."""
 
+    PRECISIONS = {"fp16": {}, "split": {"ANCE_ENCODER_SPLIT": "1"}, "fp32": {"ANCE_ENCODER_PRECISE": "1"}}
+
     def __init__(self, state_dict, arch=ARCH_ROBERTA, prefix="roberta.", has_head=True, pad_token_id=None,
-                 ln_eps=None, max_seq_len=512, max_tokens=65536, device=None):
+                 ln_eps=None, max_seq_len=512, max_tokens=65536, device=None, precision=None):
+        """precision: None = whatever ANCE_ENCODER_SPLIT / ANCE_ENCODER_PRECISE say (include/ance_amd.h); "fp16" = the
+        default mode (fp16 MFMA operands, 3e-3), "split" = fp16-pair operands, fp32-grade (2e-5, ~2.6 x slower), "fp32" = fp32
+        operands (the audit path, ~9 x slower).  The library reads the mode when the handle is created."""
         import torch
         L = _lib.lib()
+        if precision is not None:
+            if precision not in self.PRECISIONS:
+                raise ValueError("precision must be one of %s" % sorted(self.PRECISIONS))
+            saved = {k: os.environ.pop(k, None) for k in ("ANCE_ENCODER_SPLIT", "ANCE_ENCODER_PRECISE")}
+            os.environ.update(self.PRECISIONS[precision])
+            try:
+                self.__init__(state_dict, arch, prefix, has_head, pad_token_id, ln_eps, max_seq_len, max_tokens, device, None)
+            finally:
+                for k in ("ANCE_ENCODER_SPLIT", "ANCE_ENCODER_PRECISE"):
+                    os.environ.pop(k, None)
+                    if saved[k] is not None:
+                        os.environ[k] = saved[k]
+            self.precision = precision
+            return
+        self.precision = "fp32" if os.environ.get("ANCE_ENCODER_PRECISE", "")[:1] == "1" else \
+            ("split" if os.environ.get("ANCE_ENCODER_SPLIT", "")[:1] == "1" else "fp16")
         self.device = torch.device(device if device is not None else "cuda")
         n_layers = count_layers(state_dict, prefix)
         if n_layers == 0:
@@ -182,6 +203,38 @@ class AnceModel:
     def query_emb(self, input_ids, attention_mask):
         return self.q.embed(input_ids, attention_mask)
 
+    def forward(self, query_ids, attention_mask_q, input_ids_a=None, attention_mask_a=None, input_ids_b=None,
+                attention_mask_b=None, is_query=True):
+        """NLL.forward / NLL_MultiChunk.forward (model/models.py:57-81, 84-134), forward only: with one input the embedding
+        (query or body tower); with a triplet ``(loss.mean(),)`` -- three encodes on the HIP encoder and the fused dot /
+        max-over-chunks / 2-way log-softmax kernel ``ance_nll_forward``.  ``self.last_logits`` / ``self.last_loss_rows`` keep the
+        per-triplet values of the last call (CUDA tensors)."""
+        import torch
+        if input_ids_b is None and is_query:
+            return self.query_emb(query_ids, attention_mask_q)
+        if input_ids_b is None:
+            return self.body_emb(query_ids, attention_mask_q)
+        q = self.query_emb(query_ids, attention_mask_q).contiguous()
+        a = self.body_emb(input_ids_a, attention_mask_a).contiguous()
+        b = self.body_emb(input_ids_b, attention_mask_b).contiguous()
+        n, d, chunks = q.shape[0], q.shape[1], self.chunks
+        ma = mb = None
+        if chunks > 1:
+            ma = attention_mask_a.to(q.device).reshape(n, chunks, -1)[:, :, 0].to(torch.float32).contiguous()
+            mb = attention_mask_b.to(q.device).reshape(n, chunks, -1)[:, :, 0].to(torch.float32).contiguous()
+        logits = torch.empty((n, 2), dtype=torch.float32, device=q.device)
+        rows = torch.empty((n,), dtype=torch.float32, device=q.device)
+        mean = torch.empty((1,), dtype=torch.float32, device=q.device)
+        P = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None  # noqa: E731
+        with torch.cuda.device(q.device):
+            rc = _lib.lib().ance_nll_forward(P(q), P(a), P(b), P(ma), P(mb), n, d, chunks, P(logits), P(rows), P(mean),
+                                             _lib.current_stream_ptr())
+        _lib.check(rc, "ance_nll_forward")
+        self.last_logits, self.last_loss_rows = logits, rows
+        return (mean[0],)
+
+    __call__ = forward
+
     def body_emb(self, input_ids, attention_mask):
         if self.chunks == 1:
             return self.b.embed(input_ids, attention_mask)
@@ -203,8 +256,8 @@ def load_hf_state_dict(ckpt_dir):
     raise FileNotFoundError("no model.safetensors / pytorch_model.bin in %s" % ckpt_dir)
 
 
-def load_model(model_type, checkpoint_path, max_seq_length=128, max_tokens=65536, device=None):
-    """Registry of model/models.py:299-322 restricted to the encoders on the path."""
+def load_model(model_type, checkpoint_path, max_seq_length=128, max_tokens=65536, device=None, precision=None):
+    """Registry of model/models.py:299-322 restricted to the encoders on the path.  precision: see ``Encoder``."""
     model_type = model_type.lower()
     if model_type in ("rdot_nll", "rdot_nll_multi_chunk"):
         sd = load_hf_state_dict(checkpoint_path)
@@ -213,16 +266,17 @@ def load_model(model_type, checkpoint_path, max_seq_length=128, max_tokens=65536
         if model_type == "rdot_nll_multi_chunk":
             chunks = max(1, max_seq_length // 512)  # base_len = 512 (model/models.py:163)
             seq = 512
-        enc = Encoder(sd, ARCH_ROBERTA, "roberta.", True, max_seq_len=min(seq, 512), max_tokens=max_tokens, device=device)
+        enc = Encoder(sd, ARCH_ROBERTA, "roberta.", True, max_seq_len=min(seq, 512), max_tokens=max_tokens, device=device,
+                      precision=precision)
         return AnceModel(model_type, enc, chunks=chunks)
     if model_type == "dpr":
         import torch
         ck = torch.load(checkpoint_path, map_location="cpu", weights_only=False)
         sd = ck["model_dict"] if isinstance(ck, dict) and "model_dict" in ck else getattr(ck, "model_dict", ck)
         q = Encoder(sd, ARCH_BERT, "question_model.", False, max_seq_len=min(max_seq_length, 512), max_tokens=max_tokens,
-                    device=device)
+                    device=device, precision=precision)
         c = Encoder(sd, ARCH_BERT, "ctx_model.", False, max_seq_len=min(max_seq_length, 512), max_tokens=max_tokens,
-                    device=device)
+                    device=device, precision=precision)
         return AnceModel(model_type, q, c)
     raise ValueError("model_type %r is not on the MI355X path (supported: rdot_nll, rdot_nll_multi_chunk, dpr)" % model_type)
 

@@ -66,6 +66,18 @@ class FlatIPIndex:
         self._x = None
         self._image = None
 
+    def invalidate(self):
+        """Forget the search image of the added rows.  Call after the rows were rewritten THROUGH A RAW POINTER -- the
+        library's own ``Encoder.encode_records(out=...)`` / ``encode_ids(out=...)`` write that way, and such writes do not
+        bump the tensor version counter the image is keyed on: the filter would run on the stale fp16 rows while the exact
+        re-scoring reads the new ones, and true neighbours could be filtered out silently.  (The refresh job never reuses an
+        embedding buffer it has searched; benchmarks that re-encode into one buffer must call this.)  The old image is kept
+        alive until the searches already queued on it have finished."""
+        if getattr(self, "_image", None) is not None and self._image is not False:
+            import torch
+            self._image.record_stream(torch.cuda.current_stream(self.device))
+        self._image = None
+
     def _matrix(self):
         import torch
         if self._x is None:
@@ -98,6 +110,8 @@ class FlatIPIndex:
         # re-scoring reads the new ones
         key = (x.data_ptr(), x._version, n)
         if self._image is not None and self._image_key != key:
+            if self._image is not False:  # searches queued on another stream may still read the old image
+                self._image.record_stream(torch.cuda.current_stream(self.device))
             self._image = None
         if self._image is None:
             self._image_key = key

@@ -715,6 +715,8 @@ def main():
         out["retrieval_agreement"] = {k_: ra[k_] for k_ in keys}
         if "precise_mode" in ra:
             out["retrieval_agreement"]["fp32_mode"] = {k_: ra["precise_mode"][k_] for k_ in keys}
+        if "split_mode" in ra:
+            out["retrieval_agreement"]["split_mode"] = {k_: ra["split_mode"][k_] for k_ in keys}
         out["retrieval_agreement"]["source"] = "profiles/%s (tests/test_gpu_retrieval.py: both encoder modes against the fp32 oracle)" % src
     except Exception:
         pass

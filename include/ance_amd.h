@@ -245,6 +245,17 @@ int ance_encode_ids(AnceEncoder *enc, const int32_t *d_ids, int64_t ld_ids, cons
 int ance_debug_gemm(int ablate, int epi, const void *d_a_f16, const void *d_b_f16, int M, int N, int K,
                     const float *d_bias, void *d_out, const float *d_res32, void *stream);
 
+/* Forward of the training objective on embeddings the encoder produced -- the consumer side of the refresh's file contract
+ * (forward only): replaces the tail of NLL.forward (model/models.py:71-81) and NLL_MultiChunk.forward
+ * (:97-134) after the three query_emb / body_emb calls.
+ *   d_q [n, d], d_a / d_b [n * chunks, d] fp32 (row = triplet * chunks + chunk); chunks = 1 for FirstP;
+ *   d_mask_a / d_mask_b [n, chunks] fp32 = the attention mask's first entry of every chunk (MaxP: an all-pad chunk is biased by
+ *   -9999 before the max over chunks, :109-113); may be NULL when chunks == 1;
+ *   d_logits [n, 2] = (logit_a, logit_b); d_loss_rows [n] = -log_softmax(logits)[:, 0]; d_loss_mean [1] = their mean (fixed
+ *   summation order: the same input gives the same bits).  d a multiple of 4. */
+int ance_nll_forward(const float *d_q, const float *d_a, const float *d_b, const float *d_mask_a, const float *d_mask_b, int64_t n,
+                     int d, int chunks, float *d_logits, float *d_loss_rows, float *d_loss_mean, void *stream);
+
 /* Test hook: the SPLIT (fp32-grade) GEMM of the encoder with one of its epilogues.  acc[m][n] = sum_k a[m][k] b[n][k] with
  * a = a_hi + a_lo' 2^-11 (b likewise); d_a_pair [M, 2K] / d_b_pair [N, 2K] fp16 rows [hi (K) | lo' (K)]; (mu_m, r_m) = mean and
  * 1 / sqrt(var + ln_eps) of row m combined from d_part [M][12][2], the (mean, M2) of its twelve 64-column slices.

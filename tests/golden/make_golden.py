@@ -272,6 +272,53 @@ def golden_config1():
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+def golden_nll():
+    """The reference's training forward itself -- RobertaDot_NLL_LN.forward (NLL, model/models.py:57-81) and
+    RobertaDot_CLF_ANN_NLL_MultiChunk.forward (NLL_MultiChunk, :84-134) -- on seeded triplets: the loss it returns, and the
+    embeddings of its own query_emb / body_emb for the logits (2 layers / 1 layer, deterministic weights)."""
+    rng = np.random.default_rng(404)
+    out = {}
+    arrays = {}
+    # FirstP: 12 triplets, Lq = 32, L = 64
+    w1 = dict(seed=51, n_layers=2, ln_jitter=0.1)
+    sd = encoder_ref.det_state_dict(**w1)
+    m = ref_harness.build_reference_model("rdot_nll", n_layers=2, seed=0)
+    load_into(m, sd)
+    n = 12
+    ql = synth.lognormal_lengths(rng, n, 9, 0.35, 4, 32)
+    al = synth.lognormal_lengths(rng, n, 40, 0.45, 8, 64)
+    bl = synth.lognormal_lengths(rng, n, 40, 0.45, 8, 64)
+    qi, ai, bi = synth.make_records(rng, n, 32, ql), synth.make_records(rng, n, 64, al), synth.make_records(rng, n, 64, bl)
+    ai[:6, 1:6] = qi[:6, 1:6]  # the positive shares tokens with the query for half of the triplets
+    T = lambda x: torch.from_numpy(x).long()
+    M = encoder_ref.mask_from_lengths
+    with torch.no_grad():
+        loss = m(T(qi), M(ql, 32), T(ai), M(al, 64), T(bi), M(bl, 64))[0]
+        q, a, b = m.query_emb(T(qi), M(ql, 32)), m.body_emb(T(ai), M(al, 64)), m.body_emb(T(bi), M(bl, 64))
+    arrays.update(f_q_ids=qi, f_q_len=ql, f_a_ids=ai, f_a_len=al, f_b_ids=bi, f_b_len=bl, f_q=q.numpy(), f_a=a.numpy(), f_b=b.numpy())
+    out["firstp"] = dict(weights=dict(gen="det", checksum=sd_checksum(sd), **w1), loss=float(loss))
+    # MaxP: 6 triplets, documents of 1-4 chunks (all-pad chunks are biased out by -9999)
+    w2 = dict(seed=52, n_layers=1, ln_jitter=0.1)
+    sd2 = encoder_ref.det_state_dict(**w2)
+    m2 = ref_harness.build_reference_model("rdot_nll_multi_chunk", n_layers=1, seed=0)
+    load_into(m2, sd2)
+    n2 = 6
+    ql2 = synth.lognormal_lengths(rng, n2, 9, 0.35, 4, 32)
+    al2 = np.array([2048, 700, 512, 30, 1300, 513], dtype=np.int64)
+    bl2 = np.array([100, 2048, 1025, 513, 40, 1536], dtype=np.int64)
+    qi2, ai2, bi2 = synth.make_records(rng, n2, 32, ql2), synth.make_records(rng, n2, 2048, al2), synth.make_records(rng, n2, 2048, bl2)
+    with torch.no_grad():
+        loss2 = m2(T(qi2), M(ql2, 32), T(ai2), M(al2, 2048), T(bi2), M(bl2, 2048))[0]
+        q2, a2, b2 = m2.query_emb(T(qi2), M(ql2, 32)), m2.body_emb(T(ai2), M(al2, 2048)), m2.body_emb(T(bi2), M(bl2, 2048))
+    arrays.update(m_q_ids=qi2, m_q_len=ql2, m_a_ids=ai2, m_a_len=al2, m_b_ids=bi2, m_b_len=bl2, m_q=q2.numpy(), m_a=a2.numpy(),
+                  m_b=b2.numpy())
+    out["maxp"] = dict(weights=dict(gen="det", checksum=sd_checksum(sd2), **w2), loss=float(loss2))
+    np.savez_compressed(os.path.join(OUT, "nll.npz"), **arrays)
+    with open(os.path.join(OUT, "nll.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    return {k: v["loss"] for k, v in out.items()}
+
+
 def golden_dpr():
     """validate / GenerateNegativePassaageID / has_answer of the reference's DPR driver on synthetic
     passages and answers (unicode, punctuation, multi-token and empty-token answers)."""
@@ -396,7 +443,7 @@ def golden_metrics():
 if __name__ == "__main__":
     torch.set_num_threads(8)
     makers = dict(encoder=golden_encoder, postsearch=golden_postsearch, e2e=golden_end_to_end, e2e_maxp=golden_end_to_end_maxp,
-                  config1=golden_config1,
+                  config1=golden_config1, nll=golden_nll,
                   dpr=golden_dpr, preprocess=golden_preprocess, metrics=golden_metrics, dpr_preprocess=golden_dpr_preprocess)
     which = sys.argv[1:] or list(makers)  # `make_golden.py e2e_maxp` regenerates one piece and its manifest entry
     mpath = os.path.join(OUT, "manifest.json")

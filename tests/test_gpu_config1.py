@@ -148,8 +148,6 @@ def _run_job(c1, mode_env, run_name, tmp_path, monkeypatch):
     from ance_amd.encoder import load_model
     for k in ("ANCE_ENCODER_PRECISE", "ANCE_ENCODER_SPLIT"):
         monkeypatch.delenv(k, raising=False)
-    for k, v in mode_env.items():
-        monkeypatch.setenv(k, v)
     a = c1.e["runs"][run_name]["args"]
     out = str(tmp_path / ("out_" + run_name))
     args = types.SimpleNamespace(
@@ -157,7 +155,8 @@ def _run_job(c1, mode_env, run_name, tmp_path, monkeypatch):
         output_dir=out, cache_dir=out, model_type="rdot_nll", end_output_num=a["output_num"], max_seq_length=a["max_seq_length"],
         max_query_length=a["max_query_length"], ann_chunk_factor=a["ann_chunk_factor"], topk_training=a["topk_training"],
         negative_sample=a["negative_sample"], ann_measure_topk_mrr=a["ann_measure_topk_mrr"],
-        only_keep_latest_embedding_file=False, inference=False, device=torch.device("cuda"), max_tokens=16384)
+        only_keep_latest_embedding_file=False, inference=False, device=torch.device("cuda"), max_tokens=16384,
+        encoder_precision=mode_env)
     # the poll loop numbers its outputs from the files present: pre-create the earlier outputs the reference run implies
     os.makedirs(out, exist_ok=True)
     for n in range(a["output_num"]):
@@ -169,7 +168,8 @@ def _run_job(c1, mode_env, run_name, tmp_path, monkeypatch):
     adg.ann_data_gen(args)
     no, train_path, nd = adg.get_latest_ann_data(out)
     assert no == a["output_num"]
-    model = load_model("rdot_nll", str(c1.ckpt), max_seq_length=a["max_seq_length"], max_tokens=16384)
+    model = load_model("rdot_nll", str(c1.ckpt), max_seq_length=a["max_seq_length"], max_tokens=16384, precision=mode_env)
+    assert model.q.precision == mode_env
     eng = adg.HipEngine()
 
     def emb(name, is_q):
@@ -189,11 +189,7 @@ def _negs(rest):
     return int(pos), [int(x) for x in negs.split(",")] if negs else []
 
 
-MODES = {
-    "fp32": {"ANCE_ENCODER_PRECISE": "1"},
-    "split": {"ANCE_ENCODER_SPLIT": "1"},
-    "default": {},
-}
+MODES = {"fp32": "fp32", "split": "split", "default": "fp16"}  # --encoder_precision of ance_amd.ann_data_gen
 
 
 @pytest.mark.parametrize("mode", ["fp32", "split", "default"])

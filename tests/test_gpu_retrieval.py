@@ -107,9 +107,13 @@ def test_retrieval_agreement_fp16_operands_vs_fp32_reference(monkeypatch):
     monkeypatch.setenv("ANCE_ENCODER_PRECISE", "1")
     res_p = agreement(*encode_all())
     monkeypatch.delenv("ANCE_ENCODER_PRECISE", raising=False)
+    # split mode (fp16 pair operands, three MFMA passes): fp32-grade at a third of the fp16 rate
+    monkeypatch.setenv("ANCE_ENCODER_SPLIT", "1")
+    res_s = agreement(*encode_all())
+    monkeypatch.delenv("ANCE_ENCODER_SPLIT", raising=False)
     os.makedirs(OUT, exist_ok=True)
     with open(os.path.join(OUT, "retrieval_agreement.json"), "w") as f:
-        json.dump(dict(res, precise_mode=res_p), f, indent=1)
+        json.dump(dict(res, precise_mode=res_p, split_mode=res_s), f, indent=1)
     assert res["max_abs_passage"] <= 5e-3 and res["max_abs_query"] <= 5e-3, res
     assert res["recall_at_200"] >= 0.985, res
     assert res["first_20_negatives_overlap"] >= 0.97, res
@@ -117,3 +121,6 @@ def test_retrieval_agreement_fp16_operands_vs_fp32_reference(monkeypatch):
     assert res_p["max_abs_passage"] <= 5e-5 and res_p["max_abs_query"] <= 5e-5, res_p
     assert res_p["recall_at_200"] >= 0.9995, res_p
     assert res_p["identical_first_20_negatives"] >= 0.9, res_p
+    assert res_s["max_abs_passage"] <= 2e-5 and res_s["max_abs_query"] <= 2e-5, res_s
+    assert res_s["recall_at_200"] >= 0.9995, res_s
+    assert res_s["identical_first_20_negatives"] >= 0.95, res_s
