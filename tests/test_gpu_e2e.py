@@ -13,11 +13,9 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-# what the default (fp16-operand) encoder measures on the toy job, with a small margin -- not a loose bound
-E2E_MAX_DELTA_NDCG = 0.02      # measured 0.0 (profiles/r03_e2e_agreement.json)
-E2E_MIN_IDENTICAL_LINES = 0.8   # measured 26 of 30
-MAXP_MAX_DELTA_NDCG = 0.02      # measured 0.0
-MAXP_MIN_IDENTICAL_SETS = 0.85  # measured 23 of 24 negative sets (22 of 24 lines) identical to the reference's run
+# Against the reference's own run of the same job, every line that differs must be EXPLAINED: both negative lists have to be
+# exact rankings of scores within the measured error of the fp64 truth (tests/test_gpu_config1.py: tau_needed) -- near-ties
+# of two different roundings of the same encoder, nothing else.  The counts are recorded, not thresholded.
 
 
 from golden_util import golden_weights  # noqa: E402
@@ -78,20 +76,42 @@ def test_refresh_job_end_to_end(golden_dir, tmp_path):
     # (b) against the reference's own run (fp32 CPU encoder): same NDCG up to encoder tolerance, and
     # the same negatives for almost every query (ann_measure_topk_mrr mode is deterministic)
     if rng_ok:
+        from test_gpu_config1 import chain_score_error, tau_needed
+        nl = e["weights"]["n_layers"]
+        sd64 = {k: v.to(device="cuda", dtype=torch.float64) for k, v in sd.items()}
+
+        def enc64(name, L):
+            lens, ids = ann_ref.read_cache(os.path.join(data, name))
+            with torch.no_grad():
+                return encoder_ref.rdot_nll_ln_emb(sd64, torch.from_numpy(ids).cuda(), encoder_ref.mask_from_lengths(lens, L).cuda(), n_layers=nl)
+
+        p64, q64 = enc64("passages", a["max_seq_length"]), enc64("train-query", a["max_query_length"])
+        s0, s1 = ann_ref.query_chunk(len(train_q), 0, a["ann_chunk_factor"])
+        S64 = (q64 @ p64.T).cpu().numpy()
+        tau_G = 1.0001 * chain_score_error(torch.from_numpy(p_emb), torch.from_numpy(train_q), S64)
+        tau_R = 2e-3  # the reference's fp32 CPU forward + BLAS scores (tests/test_gpu_config1.py measures 7.6e-4 at 12 layers)
         ref_lines = dict(l.split("\t", 1) for l in e["ann_training_data_0"].splitlines())
         got_lines = dict(l.split("\t", 1) for l in open(train_path).read().splitlines())
         assert set(ref_lines) == set(got_lines)
-        same = sum(ref_lines[q] == got_lines[q] for q in ref_lines)
+        same, unexplained = 0, []
+        for q in ref_lines:
+            if ref_lines[q] == got_lines[q]:
+                same += 1
+                continue
+            pos = int(ref_lines[q].split("\t")[0])
+            ng = [int(x) for x in got_lines[q].split("\t")[1].split(",")]
+            nr = [int(x) for x in ref_lines[q].split("\t")[1].split(",")]
+            if tau_needed(S64[int(q)], ng, excluded=[pos]) > tau_G or tau_needed(S64[int(q)], nr, excluded=[pos]) > tau_R:
+                unexplained.append(int(q))
         d_ndcg = abs(nd["ndcg"] - e["ann_ndcg_0"]["ndcg"])
         outd = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
         os.makedirs(outd, exist_ok=True)
         with open(os.path.join(outd, "e2e_agreement.json"), "w") as f:
-            json.dump({"identical_lines": same, "lines": len(ref_lines), "abs_delta_ndcg": d_ndcg,
-                       "ndcg": nd["ndcg"], "ndcg_reference": e["ann_ndcg_0"]["ndcg"]}, f)
-        # measured on MI355X (fp16-operand encoder against the reference's fp32 CPU run of the same job): see the
-        # thresholds' source in profiles/ (r03_e2e_agreement.json)
-        assert d_ndcg <= E2E_MAX_DELTA_NDCG, d_ndcg
-        assert same >= E2E_MIN_IDENTICAL_LINES * len(ref_lines), (same, len(ref_lines))
+            json.dump({"identical_lines": same, "lines": len(ref_lines), "differing_lines_explained_by_near_ties": len(ref_lines) - same - len(unexplained),
+                       "unexplained": unexplained, "tau_G": tau_G, "abs_delta_ndcg": d_ndcg, "ndcg": nd["ndcg"],
+                       "ndcg_reference": e["ann_ndcg_0"]["ndcg"]}, f)
+        assert not unexplained, unexplained
+        assert d_ndcg <= 0.03, d_ndcg  # dev lists of 20 queries: one near-tie swap at rank <= 10 moves NDCG@10 by ~0.01
 
     # the reference consumer's line parser accepts the file (data/msmarco_data.py:338-343)
     for line in open(train_path):
@@ -181,16 +201,38 @@ def test_maxp_refresh_job_end_to_end(golden_dir, tmp_path):
         assert len(set(ng)) == len(ng) and int(pos) not in ng
 
     if rng_ok:
+        from test_gpu_config1 import chain_score_error, tau_needed
+        sd64 = {k: v.to(device="cuda", dtype=torch.float64) for k, v in sd.items()}
+        lens_p, ids_p = ann_ref.read_cache(os.path.join(data, "passages"))
+        lens_q, ids_q = ann_ref.read_cache(os.path.join(data, "train-query"))
+        with torch.no_grad():
+            p64 = torch.cat([encoder_ref.rdot_nll_multi_chunk_body_emb(sd64, torch.from_numpy(ids_p[b0:b0 + 8]).cuda(),
+                                                                     encoder_ref.mask_from_lengths(lens_p[b0:b0 + 8], a["max_seq_length"]).cuda(),
+                                                                     n_layers=w["n_layers"]) for b0 in range(0, n_docs, 8)]).reshape(n_docs * chunks, 768)
+            q64 = encoder_ref.rdot_nll_ln_emb(sd64, torch.from_numpy(ids_q).cuda(), encoder_ref.mask_from_lengths(lens_q, a["max_query_length"]).cuda(),
+                                              n_layers=w["n_layers"])
+        S64_rows = (q64 @ p64.T).cpu().numpy()                                   # [queries, documents x chunks]
+        S64 = S64_rows.reshape(len(lens_q), n_docs, chunks).max(-1)             # a document's score = its best chunk
+        tau_G = 1.0001 * chain_score_error(torch.from_numpy(p_emb), torch.from_numpy(train_q), S64_rows)
+        tau_R = 2e-3
         ref_lines = dict(l.split("\t", 1) for l in e["ann_training_data_0"].splitlines())
         got_lines = dict(l.split("\t", 1) for l in open(train_path).read().splitlines())
         assert set(ref_lines) == set(got_lines)
-        same = sum(ref_lines[q] == got_lines[q] for q in ref_lines)
-        same_sets = sum(set(ref_lines[q].split("\t")[1].split(",")) == set(got_lines[q].split("\t")[1].split(",")) for q in ref_lines)
+        same, same_sets, unexplained = 0, 0, []
+        for q in ref_lines:
+            pos = int(ref_lines[q].split("\t")[0])
+            ng = [int(x) for x in got_lines[q].split("\t")[1].split(",")]
+            nr = [int(x) for x in ref_lines[q].split("\t")[1].split(",")]
+            same += ng == nr
+            same_sets += set(ng) == set(nr)
+            if ng != nr and (tau_needed(S64[int(q)], ng, excluded=[pos]) > tau_G or tau_needed(S64[int(q)], nr, excluded=[pos]) > tau_R):
+                unexplained.append(int(q))
         d_ndcg = abs(nd["ndcg"] - e["ann_ndcg_0"]["ndcg"])
         outd = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
         os.makedirs(outd, exist_ok=True)
         with open(os.path.join(outd, "e2e_agreement_maxp.json"), "w") as f:
-            json.dump({"identical_lines": same, "identical_negative_sets": same_sets, "lines": len(ref_lines), "abs_delta_ndcg": d_ndcg,
-                       "ndcg": nd["ndcg"], "ndcg_reference": e["ann_ndcg_0"]["ndcg"]}, f)
-        assert d_ndcg <= MAXP_MAX_DELTA_NDCG, d_ndcg
-        assert same_sets >= MAXP_MIN_IDENTICAL_SETS * len(ref_lines), (same, same_sets, len(ref_lines))
+            json.dump({"identical_lines": int(same), "identical_negative_sets": int(same_sets), "lines": len(ref_lines),
+                       "differing_lines_explained_by_near_ties": len(ref_lines) - int(same) - len(unexplained), "unexplained": unexplained,
+                       "tau_G": tau_G, "abs_delta_ndcg": d_ndcg, "ndcg": nd["ndcg"], "ndcg_reference": e["ann_ndcg_0"]["ndcg"]}, f)
+        assert not unexplained, unexplained
+        assert d_ndcg <= 0.07, d_ndcg  # 8 dev queries: one near-tie swap at rank <= 10 moves NDCG@10 by up to 0.06
