@@ -14,9 +14,13 @@ E="python bench.py --skip-search --no-cpu-baseline --skip-precise --steps ${PMC_
 for what in ${PMC_LEGS:-search encode}; do
   cmd="$S"; [ $what = encode ] && cmd="$E"
   [ $what = encode ] && export ANCE_ENCODER_STREAMS=1
+  if [ $what = encode_split ]; then cmd="python scripts/encode_mode_leg.py split"; export ANCE_ENCODER_STREAMS=1; fi
+  if [ $what = encode_fp32 ]; then cmd="python scripts/encode_mode_leg.py fp32 1 4096"; export ANCE_ENCODER_STREAMS=1; fi
   rx="ip_topk_fast_kernel|rescore_kernel"; [ $what = encode ] && rx="gemm256_f16_desc_kernel|attention_kernel"
+  [ $what = encode_split ] && rx="gemm256_split_kernel|attention_split_kernel"
   echo "== kernel-trace $what"
   timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/pmc/kt_$what -o kt -- $cmd > gpurun_out/pmc/kt_$what.log 2>&1; echo "rc=$?"
+  if [ $what = encode_fp32 ]; then unset ANCE_ENCODER_STREAMS; continue; fi  # the audit path: kernel trace only
   echo "== pmc cycles $what (GRBM_GUI_ACTIVE = shader clocks of the dispatch: clock-independent cost, and the clock itself)"
   timeout 900 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES --kernel-trace --kernel-include-regex "$rx" --output-format csv -d gpurun_out/pmc/CYCLES_$what -o pmc -- $cmd > gpurun_out/pmc/CYCLES_$what.log 2>&1; echo "rc=$?"
   echo "== pmc L2 hit/miss $what"
@@ -28,5 +32,18 @@ for what in ${PMC_LEGS:-search encode}; do
   done
   unset ANCE_ENCODER_STREAMS
 done
+# ---- HBM traffic of the WHOLE encode step by counters (north_star: "rocprof evidences achieved HBM GB/s on the encode sweep"): every
+# kernel of the leg, a 4,096-passage block so that a counter pass (~500 dispatches) finishes, the same block timed untraced
+if [[ " ${PMC_LEGS:-search encode} " == *" encode "* ]]; then
+  export ANCE_ENCODER_STREAMS=1
+  EA="python bench.py --skip-search --no-cpu-baseline --skip-precise --encode-block 4096 --steps 1 --warmup 1"
+  echo "== untraced step, 4,096-passage block"
+  timeout 300 $EA > gpurun_out/pmc/encode_all_plain.json 2> gpurun_out/pmc/encode_all_plain.err; echo "rc=$?"
+  for c in FETCH_SIZE WRITE_SIZE; do
+    echo "== pmc $c encode_all"
+    timeout 900 rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmc/${c}_encodeall -o pmc -- $EA > gpurun_out/pmc/${c}_encodeall.log 2>&1; echo "rc=$?"
+  done
+  unset ANCE_ENCODER_STREAMS
+fi
 find gpurun_out/pmc -name "*kernel_trace.csv" -size +8M -delete
 python scripts/summarize_pmc.py gpurun_out/pmc gpurun_out/pmc/pmc_traffic.json 2>&1 | tail -120

@@ -95,12 +95,52 @@ if len(sys.argv) > 2:
                         dur.append(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
         return (sum(dur) / len(dur), len(dur)) if dur else (None, 0)
 
+    def step_traffic():
+        """FETCH x 2 + WRITE bytes of EVERY dispatch of one encode step (the *_encodeall passes: 4,096-passage block, one
+        warm-up step and one timed step: the second half of the dispatches), and the untraced time of that step."""
+        tot = {}
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            rows = []
+            for f in glob.glob(os.path.join(root, "%s_encodeall" % counter, "**", "*counter_collection.csv"), recursive=True):
+                with open(f) as fh:
+                    for row in csv.DictReader(fh):
+                        if row.get("Counter_Name") == counter:
+                            rows.append((int(row.get("Dispatch_Id", 0) or 0), float(row.get("Counter_Value", 0) or 0), row.get("Kernel_Name", "")))
+            if not rows:
+                return None
+            rows.sort()
+            enc = [r for r in rows if any(k in r[2] for k in ("gemm256", "attention", "embed", "head", "plan_kernel", "pack_kernel", "gather_cls"))]
+            # bench.py --steps 1 --warmup 1 runs the block four times (warm-up + timed step, then the same on the single-stream
+            # roofline handle): the last quarter of the encoder dispatches is one step
+            half = enc[len(enc) - len(enc) // 4:]
+            tot[counter] = sum(v for _, v, _ in half) * 1024.0
+            tot[counter + "_dispatches"] = len(half)
+        try:
+            with open(os.path.join(root, "encode_all_plain.json")) as fh:
+                line = json.loads(fh.read().strip().splitlines()[-1])
+            ms, pps = line["ms_per_step"], line["value"]
+        except Exception:
+            return None
+        b = 2.0 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]
+        return {"block_passages": 4096, "dispatches": tot["FETCH_SIZE_dispatches"], "fetch_bytes_x2": 2.0 * tot["FETCH_SIZE"],
+                "write_bytes": tot["WRITE_SIZE"], "hbm_bytes_per_step": b, "ms_per_step_untraced_single_stream": ms,
+                "hbm_gbs_rocprof": b / (ms * 1e-3) / 1e9, "bytes_per_passage": b / 4096.0, "passages_per_sec": pps,
+                "round": os.environ.get("ANCE_ROUND", "r04"),
+                "note": "sum over every encoder dispatch of one step (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; "
+                        "FETCH_SIZE doubled per MI355X_MICROARCH.md) / the untraced time of the same step; the algorithmic minimum is "
+                        "4 + 4 L + 3072 bytes per passage -- the rest is activation round trips between the kernels of a layer"}
+
     out = {}
+    st = step_traffic()
+    if st:
+        out.setdefault("encode", {})["whole_step"] = st
     # template arguments of gemm256_f16_desc_kernel: gemm_f16.h (4 = RESLN: attention.output.dense and output.dense, 5 = QK_F,
     # 6 = GELU_F: intermediate.dense, 7 = VT_F)
     for leg, cat, needle in (("encode", "gemm_ffn1", "gemm256_f16_desc_kernel<6"), ("encode", "gemm_qk", "gemm256_f16_desc_kernel<5"),
                              ("encode", "gemm_res", "gemm256_f16_desc_kernel<4"), ("encode", "gemm_vt", "gemm256_f16_desc_kernel<7"),
                              ("encode", "attention", "attention_kernel"),
+                             ("encode_split", "gemm_ffn1", "gemm256_split_kernel<9"), ("encode_split", "gemm_qkv", "gemm256_split_kernel<8"),
+                             ("encode_split", "gemm_res", "gemm256_split_kernel<10"), ("encode_split", "attention", "attention_split_kernel"),
                              ("search", "ip_topk_fast", "ip_topk_fast_kernel<false, false>"), ("search", "ip_topk_rescore", "rescore_kernel"),
                              ("search", "ip_topk_scan", "ip_topk_scan_kernel")):
         fe, wr = per_dispatch(leg, "FETCH_SIZE", needle), per_dispatch(leg, "WRITE_SIZE", needle)
@@ -110,7 +150,7 @@ if len(sys.argv) > 2:
         out.setdefault(leg, {})[cat] = {"cycles": cycles(leg, needle), "l2_hit_rate": l2_hit(leg, needle),
                                         "kernel_trace_avg_ns": avg_ns, "kernel_trace_dispatches": n_disp,
                                         "hbm_bytes_per_launch": 2.0 * fe + wr, "fetch_bytes_x2": 2.0 * fe, "write_bytes": wr,
-                                        "round": os.environ.get("ANCE_ROUND", "r03"),
+                                        "round": os.environ.get("ANCE_ROUND", "r04"),
                                         "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / TCC_HIT,MISS / cycles (separate passes) on the bench.py leg "
                                                 "itself (scripts/gpu_pmc.sh); FETCH_SIZE doubled per MI355X_MICROARCH.md (wide reads on gfx950)"}
     with open(sys.argv[2], "w") as f:
