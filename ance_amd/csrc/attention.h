@@ -16,8 +16,7 @@ struct AttnArgs {
 };
 
 size_t attention_lds_bytes(int max_seq_len, int n_waves);
-// split (fp32-grade) mode: fp32 Q | K | V rows in, fp16 pair rows out; ANCE_E_INVALID when the longest sequence needs more LDS
-// than a CU has (more than 256 tokens): the caller falls back to precise32.h's vector-unit kernel
+// split (fp32-grade) mode: fp32 Q | K | V rows in, fp16 pair rows out; any sequence length
 int launch_attention_split(const float *qkv, _Float16 *ctx_pair, const int4 *desc, int n_seq, int n_heads, int max_seq_len,
                            int cls_only, hipStream_t stream);
 int launch_attention(const AttnArgs &args, int n_seq, int max_seq_len, hipStream_t stream);

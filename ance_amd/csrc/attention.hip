@@ -268,61 +268,72 @@ __global__ void __launch_bounds__(64 * NW, 3) attention_kernel(const AttnArgs A)
 // split while it is staged (v = hi + lo' 2^-11, as in the split GEMM) and every product is three MFMAs:
 //     S^T = 2^-11 (K_hi Q_lo'^T + K_lo' Q_hi^T) + K_hi Q_hi^T          (Q carries log2(e) / 8: the softmax runs on exp2)
 //     O^T = 2^-11 (V_hi P_lo'^T + V_lo' P_hi^T) + V_hi P_hi^T          (two accumulator sets, combined once at the end)
-// LDS: 4 x Tk x 64 halves + pads = 66 KB at 128 keys, 132 KB at 256: sequences of more than 256 tokens take the vector-unit
-// kernel of precise32.h (launch_attention32), which this one replaces at 10 x the speed for the lengths of config 2.
+// LDS: 4 x keys x 64 halves + pads = 66 KB at 128 keys, 132 KB at 256; longer sequences stage their keys 256 at a time (the
+// online softmax iterates key blocks anyway) and re-stage them for every pass of 128 queries.  Replaces the vector-unit kernel of
+// precise32.h (launch_attention32, kept behind ANCE_SPLIT_ATTN=0) at 8 x the speed for the lengths of config 2.
 template <int NW>
 __global__ void __launch_bounds__(64 * NW, 2) attention_split_kernel(const float *qkv, _Float16 *ctx_pair, const int4 *desc, int n_heads,
-                                                                  int cls_only) {
+                                                                     int cls_only, int kchunk) {
     extern __shared__ __attribute__((aligned(16))) float smem_f[];
     const int u = blockIdx.x / n_heads;
     const int h = blockIdx.x - u * n_heads;
     const int4 dsc = desc[u];
     const int tok0 = dsc.x, T = dsc.y, s = dsc.w;
     const int Tk = (T + 31) & ~31;
-    const int vld = Tk + 4;
-    _Float16 *Kh = reinterpret_cast<_Float16 *>(smem_f);  // [Tk][64] chunk-swizzled
-    _Float16 *Kl = Kh + (size_t)Tk * HD;
-    _Float16 *Vh = Kl + (size_t)Tk * HD;                  // [64][vld]
+    // keys are staged kc keys at a time (kchunk = the launch's LDS budget, a multiple of 32): all of them at once for the
+    // sequences that fit (every sequence of config 2), 256 at a time for longer ones -- the online softmax does not care
+    const int kc = Tk < kchunk ? Tk : kchunk;
+    const int vld = kc + 4;
+    _Float16 *Kh = reinterpret_cast<_Float16 *>(smem_f);  // [kc][64] chunk-swizzled
+    _Float16 *Kl = Kh + (size_t)kc * HD;
+    _Float16 *Vh = Kl + (size_t)kc * HD;                  // [64][vld]
     _Float16 *Vl = Vh + (size_t)HD * vld;
     const int tid = threadIdx.x;
     const int w = tid >> 6, l = tid & 63, g = l >> 5, i = l & 31;
     constexpr int NT = 64 * NW;
     const int ld = 3 * n_heads * HD;
     constexpr float SC = 2048.0f, SI = 1.0f / 2048.0f;
-    // ---- stage K (rows = keys) and V^T (rows = head dims), split on the way; keys >= T are zeros ----
-    for (int e = tid; e < Tk * 8; e += NT) {
-        const int key = e >> 3, ch = e & 7;
-        f32x4 k0 = {0.f, 0.f, 0.f, 0.f}, k1 = k0, v0 = k0, v1 = k0;
-        if (key < T) {
-            const float *kp = qkv + (size_t)(tok0 + key) * ld + n_heads * HD + h * HD + ch * 8;
-            k0 = *reinterpret_cast<const f32x4 *>(kp);
-            k1 = *reinterpret_cast<const f32x4 *>(kp + 4);
-            v0 = *reinterpret_cast<const f32x4 *>(kp + n_heads * HD);
-            v1 = *reinterpret_cast<const f32x4 *>(kp + n_heads * HD + 4);
-        }
-        const f16x4 a0 = cvt_f16x4_pinned(k0), a1 = cvt_f16x4_pinned(k1), b0 = cvt_f16x4_pinned(v0), b1 = cvt_f16x4_pinned(v1);
-        f16x8 kh, kl;
+    // ---- stage K (rows = keys) and V^T (rows = head dims) of keys [k0, k0 + kc), split on the way; keys >= T are zeros ----
+    auto stage = [&](int k0) {
+        for (int e = tid; e < kc * 8; e += NT) {
+            const int kl_ = e >> 3, ch = e & 7, key = k0 + kl_;
+            f32x4 k0v = {0.f, 0.f, 0.f, 0.f}, k1v = k0v, v0 = k0v, v1 = k0v;
+            if (key < T) {
+                const float *kp = qkv + (size_t)(tok0 + key) * ld + n_heads * HD + h * HD + ch * 8;
+                k0v = *reinterpret_cast<const f32x4 *>(kp);
+                k1v = *reinterpret_cast<const f32x4 *>(kp + 4);
+                v0 = *reinterpret_cast<const f32x4 *>(kp + n_heads * HD);
+                v1 = *reinterpret_cast<const f32x4 *>(kp + n_heads * HD + 4);
+            }
+            const f16x4 a0 = cvt_f16x4_pinned(k0v), a1 = cvt_f16x4_pinned(k1v), b0 = cvt_f16x4_pinned(v0), b1 = cvt_f16x4_pinned(v1);
+            f16x8 kh, kl;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            kh[j] = a0[j]; kh[4 + j] = a1[j];
-            kl[j] = (_Float16)((k0[j] - (float)a0[j]) * SC);
-            kl[4 + j] = (_Float16)((k1[j] - (float)a1[j]) * SC);
-        }
-        *reinterpret_cast<f16x8 *>(Kh + key * HD + kswz(key, ch) * 8) = kh;
-        *reinterpret_cast<f16x8 *>(Kl + key * HD + kswz(key, ch) * 8) = kl;
+            for (int j = 0; j < 4; ++j) {
+                kh[j] = a0[j]; kh[4 + j] = a1[j];
+                kl[j] = (_Float16)((k0v[j] - (float)a0[j]) * SC);
+                kl[4 + j] = (_Float16)((k1v[j] - (float)a1[j]) * SC);
+            }
+            *reinterpret_cast<f16x8 *>(Kh + kl_ * HD + kswz(kl_, ch) * 8) = kh;
+            *reinterpret_cast<f16x8 *>(Kl + kl_ * HD + kswz(kl_, ch) * 8) = kl;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            Vh[(ch * 8 + j) * vld + key] = b0[j];
-            Vh[(ch * 8 + 4 + j) * vld + key] = b1[j];
-            Vl[(ch * 8 + j) * vld + key] = (_Float16)((v0[j] - (float)b0[j]) * SC);
-            Vl[(ch * 8 + 4 + j) * vld + key] = (_Float16)((v1[j] - (float)b1[j]) * SC);
+            for (int j = 0; j < 4; ++j) {
+                Vh[(ch * 8 + j) * vld + kl_] = b0[j];
+                Vh[(ch * 8 + 4 + j) * vld + kl_] = b1[j];
+                Vl[(ch * 8 + j) * vld + kl_] = (_Float16)((v0[j] - (float)b0[j]) * SC);
+                Vl[(ch * 8 + 4 + j) * vld + kl_] = (_Float16)((v1[j] - (float)b1[j]) * SC);
+            }
         }
+    };
+    const bool single = Tk <= kc;  // one chunk: staged once, shared by every query pass
+    if (single) {
+        stage(0);
+        __syncthreads();
     }
-    __syncthreads();
     const int q_end = cls_only ? 1 : T;
-    const int nkb = Tk >> 5;
     const float qscale = 0.125f * 1.44269504088896340736f;
-    for (int qb0 = w * 32; qb0 < q_end; qb0 += 32 * NW) {
+    for (int qp0 = 0; qp0 < q_end; qp0 += 32 * NW) {  // query pass: 32 queries per wave (uniform loop: the barriers below)
+        const int qb0 = qp0 + w * 32;
+        const bool active = qb0 < q_end;
         // Q fragments (B operand: lane (query i, group g) holds head dims 32 g + 8 sx .. + 8), scaled, then split
         f16x8 qh[4], ql[4];
         {
@@ -343,68 +354,78 @@ __global__ void __launch_bounds__(64 * NW, 2) attention_split_kernel(const float
         }
         float m_run = -INFINITY, l_run = 0.0f;
         f32x16 om0 = {0}, om1 = {0}, oc0 = {0}, oc1 = {0};
-        for (int kb = 0; kb < nkb; ++kb) {
-            const int krow = kb * 32 + i;
-            const int ksw = (krow >> 1) & 7;
-            f32x16 st = {0};
-            f16x8 kfh[4];
-#pragma unroll
-            for (int sx = 0; sx < 4; ++sx) {
-                kfh[sx] = *reinterpret_cast<const f16x8 *>(Kh + krow * HD + (((4 * g + sx) ^ ksw) * 8));
-                const f16x8 kfl = *reinterpret_cast<const f16x8 *>(Kl + krow * HD + (((4 * g + sx) ^ ksw) * 8));
-                st = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfh[sx], ql[sx], st, 0, 0, 0);
-                st = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfl, qh[sx], st, 0, 0, 0);
+        for (int k0 = 0; k0 < Tk; k0 += kc) {
+            if (!single) {
+                __syncthreads();  // the previous chunk (or pass) is no longer read
+                stage(k0);
+                __syncthreads();
             }
-            st *= SI;
+            if (!active) continue;
+            const int nkb = min(kc, Tk - k0) >> 5;
+            for (int kb = 0; kb < nkb; ++kb) {
+                const int krow = kb * 32 + i;
+                const int ksw = (krow >> 1) & 7;
+                f32x16 st = {0};
+                f16x8 kfh[4];
 #pragma unroll
-            for (int sx = 0; sx < 4; ++sx) st = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfh[sx], qh[sx], st, 0, 0, 0);
-            const int key_base = kb * 32 + 4 * g;
-            float bm = -INFINITY;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = key_base + (r & 3) + 8 * (r >> 2);
-                if (kb == nkb - 1) st[r] = key < T ? st[r] : -INFINITY;
-                bm = fmaxf(bm, st[r]);
-            }
-            bm = fmaxf(bm, __shfl_xor(bm, 32));
-            const float m_new = fmaxf(m_run, bm);
-            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-            float psum = 0.0f;
-            float p[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                p[r] = __builtin_amdgcn_exp2f(st[r] - m_new);
-                psum += p[r];
-            }
-            l_run = l_run * alpha + psum;
-            m_run = m_new;
-            om0 *= alpha; om1 *= alpha; oc0 *= alpha; oc1 *= alpha;
-#pragma unroll
-            for (int uu = 0; uu < 2; ++uu) {
-                const f16x4 h0 = cvt_f16x4_pinned(f32x4{p[8 * uu], p[8 * uu + 1], p[8 * uu + 2], p[8 * uu + 3]});
-                const f16x4 h1 = cvt_f16x4_pinned(f32x4{p[8 * uu + 4], p[8 * uu + 5], p[8 * uu + 6], p[8 * uu + 7]});
-                f16x8 ph, pl;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    ph[j] = h0[j]; ph[4 + j] = h1[j];
-                    pl[j] = (_Float16)((p[8 * uu + j] - (float)h0[j]) * SC);
-                    pl[4 + j] = (_Float16)((p[8 * uu + 4 + j] - (float)h1[j]) * SC);
+                for (int sx = 0; sx < 4; ++sx) {
+                    kfh[sx] = *reinterpret_cast<const f16x8 *>(Kh + krow * HD + (((4 * g + sx) ^ ksw) * 8));
+                    const f16x8 kfl = *reinterpret_cast<const f16x8 *>(Kl + krow * HD + (((4 * g + sx) ^ ksw) * 8));
+                    st = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfh[sx], ql[sx], st, 0, 0, 0);
+                    st = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfl, qh[sx], st, 0, 0, 0);
                 }
-                const int kc = kb * 32 + 16 * uu + 4 * g;
-                auto vfrag = [&](const _Float16 *V, int row) {
-                    const _Float16 *vp = V + row * vld + kc;
-                    const f16x4 a = *reinterpret_cast<const f16x4 *>(vp), b = *reinterpret_cast<const f16x4 *>(vp + 8);
-                    return f16x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
-                };
-                const f16x8 v0h = vfrag(Vh, i), v1h = vfrag(Vh, i + 32), v0l = vfrag(Vl, i), v1l = vfrag(Vl, i + 32);
-                oc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v0h, pl, oc0, 0, 0, 0);
-                oc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v0l, ph, oc0, 0, 0, 0);
-                oc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v1h, pl, oc1, 0, 0, 0);
-                oc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v1l, ph, oc1, 0, 0, 0);
-                om0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v0h, ph, om0, 0, 0, 0);
-                om1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v1h, ph, om1, 0, 0, 0);
+                st *= SI;
+#pragma unroll
+                for (int sx = 0; sx < 4; ++sx) st = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfh[sx], qh[sx], st, 0, 0, 0);
+                const int key_base = k0 + kb * 32 + 4 * g;
+                float bm = -INFINITY;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = key_base + (r & 3) + 8 * (r >> 2);
+                    if (k0 + kb * 32 + 32 > T) st[r] = key < T ? st[r] : -INFINITY;  // only the last block holds keys >= T
+                    bm = fmaxf(bm, st[r]);
+                }
+                bm = fmaxf(bm, __shfl_xor(bm, 32));
+                const float m_new = fmaxf(m_run, bm);   // finite: key 0 of block 0 is always real
+                const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+                float psum = 0.0f;
+                float p[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    p[r] = __builtin_amdgcn_exp2f(st[r] - m_new);
+                    psum += p[r];
+                }
+                l_run = l_run * alpha + psum;
+                m_run = m_new;
+                om0 *= alpha; om1 *= alpha; oc0 *= alpha; oc1 *= alpha;
+#pragma unroll
+                for (int uu = 0; uu < 2; ++uu) {
+                    const f16x4 h0 = cvt_f16x4_pinned(f32x4{p[8 * uu], p[8 * uu + 1], p[8 * uu + 2], p[8 * uu + 3]});
+                    const f16x4 h1 = cvt_f16x4_pinned(f32x4{p[8 * uu + 4], p[8 * uu + 5], p[8 * uu + 6], p[8 * uu + 7]});
+                    f16x8 ph, pl;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        ph[j] = h0[j]; ph[4 + j] = h1[j];
+                        pl[j] = (_Float16)((p[8 * uu + j] - (float)h0[j]) * SC);
+                        pl[4 + j] = (_Float16)((p[8 * uu + 4 + j] - (float)h1[j]) * SC);
+                    }
+                    const int kcol = kb * 32 + 16 * uu + 4 * g;
+                    auto vfrag = [&](const _Float16 *V, int row) {
+                        const _Float16 *vp = V + row * vld + kcol;
+                        const f16x4 a = *reinterpret_cast<const f16x4 *>(vp), b = *reinterpret_cast<const f16x4 *>(vp + 8);
+                        return f16x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+                    };
+                    const f16x8 v0h = vfrag(Vh, i), v1h = vfrag(Vh, i + 32), v0l = vfrag(Vl, i), v1l = vfrag(Vl, i + 32);
+                    oc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v0h, pl, oc0, 0, 0, 0);
+                    oc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v0l, ph, oc0, 0, 0, 0);
+                    oc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v1h, pl, oc1, 0, 0, 0);
+                    oc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v1l, ph, oc1, 0, 0, 0);
+                    om0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v0h, ph, om0, 0, 0, 0);
+                    om1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v1h, ph, om1, 0, 0, 0);
+                }
             }
         }
+        if (!active) continue;
         const float l_tot = l_run + __shfl_xor(l_run, 32);
         const float inv = 1.0f / l_tot;
         if (qb0 + i < q_end) {
@@ -437,13 +458,13 @@ size_t attention_split_lds_bytes(int max_seq_len) {
     return (size_t)2 * Tk * HD * 2 + (size_t)2 * HD * (Tk + 4) * 2;
 }
 
-// qkv [T, 3 n_heads 64] fp32 -> ctx_pair [T or n_seq, 2 n_heads 64] fp16 pair rows.  Returns ANCE_E_INVALID (without setting an
-// error) when the longest sequence does not fit the LDS: the caller then takes the vector-unit kernel.
+// qkv [T, 3 n_heads 64] fp32 -> ctx_pair [T or n_seq, 2 n_heads 64] fp16 pair rows; any sequence length (keys staged 256 at a time).
 int launch_attention_split(const float *qkv, _Float16 *ctx_pair, const int4 *desc, int n_seq, int n_heads, int max_seq_len,
                            int cls_only, hipStream_t st) {
     if (n_seq <= 0) return ANCE_OK;
-    const size_t lds = attention_split_lds_bytes(max_seq_len);
-    if (lds > 150 * 1024) return ANCE_E_INVALID;
+    const int Tk = (max_seq_len + 31) & ~31;
+    const int kchunk = Tk <= 256 ? Tk : 256;  // keys staged at a time: 66 KB at 128 (two workgroups per CU), 132 KB at 256
+    const size_t lds = attention_split_lds_bytes(kchunk);
     int dev = 0;
     (void)hipGetDevice(&dev);
     static size_t attr_set[64] = {0};
@@ -454,7 +475,8 @@ int launch_attention_split(const float *qkv, _Float16 *ctx_pair, const int4 *des
             return check_launch("attention_split attr");
         if (tracked) __atomic_store_n(&attr_set[dev], lds, __ATOMIC_RELEASE);
     }
-    hipLaunchKernelGGL((attention_split_kernel<4>), dim3((unsigned)n_seq * n_heads), dim3(256), lds, st, qkv, ctx_pair, desc, n_heads, cls_only);
+    hipLaunchKernelGGL((attention_split_kernel<4>), dim3((unsigned)n_seq * n_heads), dim3(256), lds, st, qkv, ctx_pair, desc, n_heads,
+                       cls_only, kchunk);
     return ANCE_OK;
 }
 

@@ -1022,7 +1022,7 @@ int encode_impl(AnceEncoder *e, const int32_t *base, int64_t ld, const int32_t *
                             (void)hipMemsetAsync(ctxp + (size_t)S * HP, 0, (size_t)(S_pad - S) * HP * sizeof(_Float16), st);
                         rc = e->split_attn ? launch_attention_split(LN.qkv32, ctxp, LN.desc, S, D.n_heads, maxlen, tail ? 1 : 0, st)
                                            : ANCE_E_INVALID;
-                        if (rc == ANCE_E_INVALID)  // sequences of more than 256 tokens (or ANCE_SPLIT_ATTN=0): the vector-unit kernel
+                        if (rc == ANCE_E_INVALID)  // ANCE_SPLIT_ATTN=0: the fp32 vector-unit kernel (A/B)
                             rc = launch_attention32(LN.qkv32, nullptr, LN.seq_off, S, D.n_heads, st, ctxp, tail ? 1 : 0);
                     }
                     if (rc) break;
