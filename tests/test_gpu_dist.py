@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _job(rank, world, data, ckpt, out, port, L=64, max_tokens=16384):
+def _job(rank, world, data, ckpt, out, port, L=64, max_tokens=16384, precision=None):
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
     from ance_amd import ann_data_gen as adg
@@ -28,7 +28,8 @@ def _job(rank, world, data, ckpt, out, port, L=64, max_tokens=16384):
         dist.init_process_group("gloo", rank=rank, world_size=world)
     args = types.SimpleNamespace(data_dir=data, output_dir=out, cache_dir=out, inference=False, topk_training=100,
                                  negative_sample=8, ann_chunk_factor=1, ann_measure_topk_mrr=False, model_type="rdot_nll",
-                                 max_seq_length=L, max_query_length=32, device=torch.device("cuda", 0), max_tokens=max_tokens)
+                                 max_seq_length=L, max_query_length=32, device=torch.device("cuda", 0), max_tokens=max_tokens,
+                                 encoder_precision=precision)
     train_pos, dev_pos = negatives.load_positive_ids(data)
     random.seed(4321)
     d = adg.Dist()
@@ -84,4 +85,30 @@ def test_two_rank_refresh_at_512_tokens(tmp_path):
             torch.multiprocessing.spawn(_job, args=(world, data, str(ckpt) + "/", out, port, 512, 32768), nprocs=world, join=True)
         outs[world] = {n: open(os.path.join(out, n)).read() for n in ("ann_training_data_0", "ann_ndcg_0")}
         assert outs[world]["ann_training_data_0"].count("\n") == 400
+    assert outs[2] == outs[1]
+
+
+def test_two_rank_refresh_in_split_mode_at_512_tokens(tmp_path):
+    """The same invariant for the fp32-grade split mode (--encoder_precision split), at seq_len 512 so that its long-sequence
+    attention path (keys staged 256 at a time) and several micro-batches per rank are exercised: different shard boundaries
+    mean different micro-batch compositions, and every row must still come out bit-identical (contraction is off in the split
+    epilogues for exactly this reason)."""
+    from safetensors.torch import save_file
+    from oracle import encoder_ref, synth
+    data = str(tmp_path / "data")
+    synth.make_msmarco_like(data, n_passages=2500, n_train=300, n_dev=101, L=512, Lq=32, seed=13, len_median=200, len_sigma=0.7)
+    sd = encoder_ref.random_state_dict(seed=7, n_layers=2, ln_jitter=0.1)
+    ckpt = tmp_path / "checkpoint-100"
+    ckpt.mkdir()
+    save_file({k: v.contiguous() for k, v in sd.items()}, str(ckpt / "model.safetensors"))
+    outs = {}
+    for world in (1, 2):
+        out = str(tmp_path / ("w%d" % world))
+        port = 29700 + (os.getpid() + world) % 2000
+        if world == 1:
+            _job(0, 1, data, str(ckpt) + "/", out, port, 512, 16384, "split")
+        else:
+            torch.multiprocessing.spawn(_job, args=(world, data, str(ckpt) + "/", out, port, 512, 16384, "split"), nprocs=world, join=True)
+        outs[world] = {n: open(os.path.join(out, n)).read() for n in ("ann_training_data_0", "ann_ndcg_0")}
+        assert outs[world]["ann_training_data_0"].count("\n") == 300
     assert outs[2] == outs[1]
