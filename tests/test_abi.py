@@ -58,6 +58,10 @@ def test_invalid_arguments_are_rejected_before_any_launch():
     assert rc == -1
     rc = L.ance_encode_records(None, None, None, 4, 128, 1, None, None)
     assert rc == -1
+    rc = L.ance_nll_forward(None, None, None, None, None, 4, 768, 1, None, None, None, None)
+    assert rc == -1 and b"nll" in L.ance_last_error()
+    rc = L.ance_debug_gemm_split(8, None, None, 256, 256, 128, None, None, None, None, 1e-5, None, None, None, None)
+    assert rc == -1
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
