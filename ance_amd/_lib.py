@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("ANCE_AMD_LIB") or os.path.join(_HERE, "libance_amd.so
 CSRC = os.path.join(_HERE, "csrc")
 
 ANCE_OK = 0
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 c_i32p = ctypes.POINTER(ctypes.c_int32)
 c_i64p = ctypes.POINTER(ctypes.c_int64)
@@ -78,6 +78,7 @@ SYMBOLS = {
     "ance_debug_gemm": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
                                        ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                        ctypes.c_void_p]),
+    "ance_search_bad_image_calls": (ctypes.c_int, [ctypes.POINTER(ctypes.c_ulonglong)]),
     "ance_nll_forward": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                         ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                         ctypes.c_void_p]),

@@ -134,6 +134,10 @@ __global__ void __launch_bounds__(64) idx_stamp_kernel(DedupHeader *H, int64_t n
         H->magic = DEDUP_MAGIC;
     }
 }
+// searches that found their image stamped for another matrix (or never built) and answered every chunk with the exact scan:
+// correct results, several times slower -- counted so that a caller can notice (ance_search_bad_image_calls)
+__device__ unsigned long long g_bad_image_calls = 0ull;
+
 __global__ void __launch_bounds__(256) query_mean_decide_kernel(float *mq, int d, const DedupHeader *H, QueryStat *qs, int64_t n,
                                                                 const float *x) {
     __shared__ float red[4];
@@ -155,6 +159,7 @@ __global__ void __launch_bounds__(256) query_mean_decide_kernel(float *mq, int d
         qs->mq_norm = use ? nrm : 0.0f;
         qs->use_bias = use ? 1 : 0;
         qs->bad_image = bad ? 1 : 0;
+        if (bad) atomicAdd(&g_bad_image_calls, 1ull);
     }
 }
 
@@ -1390,3 +1395,15 @@ int ip_topk_fast(const float *d_x, int64_t n, int64_t row_base, const void *d_in
 }
 
 }  // namespace ance
+
+// include/ance_amd.h: how many ance_ip_topk_indexed calls (per launch chunk) on the current device ignored their image.
+// Synchronises the device (a diagnostic, not a data-path call).
+extern "C" int ance_search_bad_image_calls(unsigned long long *out) {
+    using namespace ance;
+    if (!out) {
+        set_last_error("ance_search_bad_image_calls: invalid argument");
+        return ANCE_E_INVALID;
+    }
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bad_image_calls), sizeof(*out)) != hipSuccess) return check_launch("ance_search_bad_image_calls");
+    return ANCE_OK;
+}

@@ -38,7 +38,7 @@ extern "C" {
 #define ANCE_E_LAUNCH (-3)    /* HIP reported a launch error */
 #define ANCE_E_NOMEM (-4)
 
-#define ANCE_ABI_VERSION 2
+#define ANCE_ABI_VERSION 3  /* 3: + ance_nll_forward, ance_search_bad_image_calls, ance_debug_gemm_split; split encoder mode */
 int ance_abi_version(void);
 /* last HIP error string seen by this library on the calling thread ("" if none) */
 const char *ance_last_error(void);
@@ -244,6 +244,11 @@ int ance_encode_ids(AnceEncoder *enc, const int32_t *d_ids, int64_t ld_ids, cons
  */
 int ance_debug_gemm(int ablate, int epi, const void *d_a_f16, const void *d_b_f16, int M, int N, int K,
                     const float *d_bias, void *d_out, const float *d_res32, void *stream);
+
+/* Diagnostic: the number of ance_ip_topk_indexed launch chunks on the current device whose search image did not carry the stamp
+ * of the matrix searched (moved / copied rows, a view at another address, a buffer that was never built).  Such calls are
+ * answered by the exact scan -- same results, several times slower -- and nothing else reports it.  Synchronises the device. */
+int ance_search_bad_image_calls(unsigned long long *out);
 
 /* Forward of the training objective on embeddings the encoder produced -- the consumer side of the refresh's file contract
  * (forward only): replaces the tail of NLL.forward (model/models.py:71-81) and NLL_MultiChunk.forward

@@ -29,7 +29,7 @@ def test_library_loads_and_exports_everything():
     raw = ctypes.CDLL(_lib.LIB_PATH)
     for name in _declared_functions():
         assert hasattr(raw, name), name
-    assert L.ance_abi_version() == _lib.ABI_VERSION == 2
+    assert L.ance_abi_version() == _lib.ABI_VERSION == 3
     assert L.ance_last_error() is not None
 
 

@@ -599,6 +599,12 @@ def test_image_of_another_matrix_is_not_trusted():
     x2d = torch.from_numpy(x2).cuda()
     qd = torch.from_numpy(q).cuda()
     L = _lib.lib()
+    bad0 = ctypes.c_ulonglong()
+    _lib.check(L.ance_search_bad_image_calls(ctypes.byref(bad0)), "ance_search_bad_image_calls")
+    idx.search(q, 50)                          # the normal path: the image matches, nothing is counted
+    bad1 = ctypes.c_ulonglong()
+    L.ance_search_bad_image_calls(ctypes.byref(bad1))
+    assert bad1.value == bad0.value
     n, k = 20000, 50
     D = torch.empty((70, k), dtype=torch.float32, device="cuda")
     I = torch.empty((70, k), dtype=torch.int64, device="cuda")
@@ -610,6 +616,9 @@ def test_image_of_another_matrix_is_not_trusted():
     torch.cuda.synchronize()
     Do, Io = search_ref.flat_ip_topk_chain(x2, q, k)
     assert np.array_equal(I.cpu().numpy(), Io) and np.array_equal(D.cpu().numpy(), Do)
+    bad2 = ctypes.c_ulonglong()
+    L.ance_search_bad_image_calls(ctypes.byref(bad2))
+    assert bad2.value == bad1.value + 1        # ... and the silent fallback is visible to whoever asks
     # a buffer that was never built (all zero) is refused the same way
     blank = torch.zeros_like(img)
     rc = L.ance_ip_topk_indexed(ctypes.c_void_p(x2d.data_ptr()), n, 0, ctypes.c_void_p(blank.data_ptr()), ctypes.c_void_p(qd.data_ptr()),
