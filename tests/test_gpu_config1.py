@@ -250,7 +250,7 @@ def test_topk_mode_job_against_the_reference_run(c1, mode, tmp_path, monkeypatch
         assert d_ndcg <= 0.03
 
 
-@pytest.mark.parametrize("mode", ["fp32"])
+@pytest.mark.parametrize("mode", ["fp32", "split"])
 def test_shuffle_mode_job_against_the_reference_run(c1, mode, tmp_path, monkeypatch):
     """Default selection (random.shuffle of the 200 positions under random.seed(0), drivers/run_ann_data_gen.py:351-390),
     --ann_chunk_factor 5, output 2 -> train queries [400, 600).  The shuffle makes a line a function of the exact ORDER of the
