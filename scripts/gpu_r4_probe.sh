@@ -1,5 +1,5 @@
 #!/bin/bash
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 mkdir -p gpurun_out
-timeout 900 python -m pytest tests/test_gpu_config1.py tests/test_gpu_search.py tests/test_gpu_dist.py -q -p no:cacheprovider 2>&1 | tail -4
-python -c "import json;d=json.load(open('gpurun_out/config1_agreement.json'));print({k:v for k,v in d.items() if k.startswith('shuffle')})"
+timeout 900 python -m pytest tests/test_gpu_search.py tests/test_gpu_dist.py -q -p no:cacheprovider -x 2>&1 | tail -5
+timeout 600 python scripts/search_exchange_probe.py 2>&1 | grep -v amdgpu.ids | tail -40
