@@ -133,26 +133,6 @@ class Dist:
         self.dist.gather(src, parts, dst=0)
         return torch.cat(parts, dim=0).to(dev) if self.rank == 0 else None
 
-    def all_reduce_max(self, t):
-        """Element-wise maximum of ``t`` over the ranks (the bounds of the two-phase search: nq floats per launch chunk)."""
-        if not self.on or self.world == 1:
-            return t
-        dev = t.device
-        src = t.cpu() if self._host_staged(t) else t.contiguous()
-        self.dist.all_reduce(src, op=self.dist.ReduceOp.MAX)
-        return src.to(dev)
-
-    def min_int(self, v):
-        """Minimum of a Python int over the ranks."""
-        if not self.on or self.world == 1:
-            return int(v)
-        import torch
-        t = torch.tensor([int(v)], dtype=torch.int64)
-        if self.dist.get_backend() != "gloo":
-            t = t.cuda()
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN)
-        return int(t.item())
-
     def broadcast_object(self, obj):
         """rank 0's ``obj`` on every rank."""
         if not self.on or self.world == 1:
@@ -218,39 +198,6 @@ class HipEngine:
             self._index = (key, idx)
         return self._index[1].search_device(q.contiguous(), k)
 
-    def _index_for(self, x, row_base):
-        from .index import FlatIPIndex
-        key = (x.data_ptr(), tuple(x.shape), int(row_base), getattr(x, "_version", 0))
-        if self._index is None or self._index[0] != key:
-            self._index = None
-            idx = FlatIPIndex(x.shape[1], device=self.device, row_base=row_base)
-            idx.add(x)
-            self._index = (key, idx)
-        return self._index[1]
-
-    def search_exchanged(self, dist, x, row_base, q, k):
-        """Exact top-k of ``q`` over this rank's shard for a corpus sharded over ``dist.world`` ranks, as a TWO-PHASE search per
-        launch chunk: scan (filter + this shard's lower bound of its k-th best exact score) -> one all-reduce(max) of nq floats
-        -> finish (only the rows that can still be in the GLOBAL top-k are re-scored).  Lists may be shorter than k; merged over
-        the ranks they are the lists of the whole corpus, bit for bit."""
-        torch = self.torch
-        idx = self._index_for(x, row_base)
-        q = q.contiguous()
-        nq = q.shape[0]
-        Ds, Is = [], []
-        q0 = 0
-        while q0 < nq:
-            c = idx.scan_max_queries(nq - q0, k)
-            c = dist.min_int(c if c > 0 else nq - q0)
-            c = max(1, min(c, nq - q0))
-            qc = q[q0:q0 + c]
-            lb = dist.all_reduce_max(idx.scan_device(qc, k))
-            D, I = idx.finish_device(qc, k, lb)
-            Ds.append(D)
-            Is.append(I)
-            q0 += c
-        return (torch.cat(Ds), torch.cat(Is)) if len(Ds) > 1 else (Ds[0], Is[0])
-
     def release_index(self):
         """Frees the cached search image (call when the shard's embeddings are about to be replaced)."""
         self._index = None
@@ -273,13 +220,7 @@ def sharded_search(engine, dist, x_local, row_base, q_all, k):
     shard-search-then-merge: utils/eval_mrr.py:137-183) -- and rank 0 gathers the merged blocks.  Per rank that is
     nq k 12 bytes received instead of world x as much with an all-gather, and nq / world merges instead of nq.
     Returns (D, I) on rank 0 and (None, None) elsewhere (only rank 0 post-processes)."""
-    # several ranks: the shards exchange one float per query between the scan and the re-scoring (ANCE_SEARCH_EXCHANGE=0: every
-    # shard answers its full top-k on its own, the form of rounds 1-3); results are identical either way
-    if dist.world > 1 and hasattr(engine, "search_exchanged") and os.environ.get("ANCE_SEARCH_EXCHANGE", "1") != "0" \
-            and q_all.shape[0] > 0:
-        D, I = engine.search_exchanged(dist, x_local, row_base, q_all, k)
-    else:
-        D, I = engine.search(x_local, row_base, q_all, k)
+    D, I = engine.search(x_local, row_base, q_all, k)
     if dist.world == 1:
         return D, I
     import torch

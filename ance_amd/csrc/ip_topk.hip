@@ -363,9 +363,7 @@ size_t ip_index_bytes(int64_t n, int d);
 int ip_index_build(const float *d_x, int64_t n, int d, void *d_index, size_t index_bytes, hipStream_t st);
 size_t ip_topk_fast_workspace_bytes(int64_t n, int64_t nq, int d, int k, bool with_index);
 int ip_topk_fast(const float *d_x, int64_t n, int64_t row_base, const void *d_index, const float *d_q, int64_t nq, int d, int k,
-                 float *d_out_d, int64_t *d_out_i, void *d_workspace, size_t workspace_bytes, hipStream_t st, int phase = 0,
-                 float *d_lb = nullptr);
-int64_t ip_topk_fast_chunk_queries(int64_t n, int64_t nq, int d, int k);
+                 float *d_out_d, int64_t *d_out_i, void *d_workspace, size_t workspace_bytes, hipStream_t st);
 void set_fast_stamps(unsigned long long *d_stamps);
 void reload_fast_knobs();
 }
@@ -467,50 +465,6 @@ extern "C" int ance_ip_topk_indexed(const float *d_x, int64_t n, int64_t row_bas
                             (hipStream_t)stream);
     if (!d_index) return ance_ip_topk(d_x, n, row_base, d_q, nq, d, k, d_out_d, d_out_i, d_workspace, workspace_bytes, stream);
     return ip_topk_exact_scan(d_x, n, row_base, d_q, nq, d, k, d_out_d, d_out_i, d_workspace, workspace_bytes, stream);
-}
-
-// ---- two-phase search for sharded corpora (include/ance_amd.h) ---------------------------------------------------------------
-namespace {
-bool two_phase_fast(const float *d_x, const void *d_index, const float *d_q, int64_t n, int64_t nq, int d, int k, void *ws) {
-    return d_index && fast_enabled() && d_x && d_q && ws && nq >= 1 && ip_topk_fast_workspace_bytes(n, nq, d, k, false) > 0 &&
-           nq <= ip_topk_fast_chunk_queries(n, nq, d, k);
-}
-__global__ void __launch_bounds__(256) fill_neg_inf_kernel(float *p, int64_t n) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) p[i] = -INFINITY;
-}
-}  // namespace
-
-extern "C" int64_t ance_ip_topk_scan_max_queries(int64_t n, int64_t nq, int d, int k) {
-    if (!fast_enabled() || nq < 1) return 0;
-    return ip_topk_fast_chunk_queries(n, nq, d, k);
-}
-
-extern "C" int ance_ip_topk_scan(const float *d_x, int64_t n, const void *d_index, const float *d_q, int64_t nq, int d, int k,
-                                 float *d_lb, void *d_workspace, size_t workspace_bytes, void *stream) {
-    if (!d_x || !d_q || !d_lb || !d_workspace || nq < 1 || n < 0 || k < 1) {
-        set_last_error("ance_ip_topk_scan: invalid argument");
-        return ANCE_E_INVALID;
-    }
-    if (two_phase_fast(d_x, d_index, d_q, n, nq, d, k, d_workspace))
-        return ip_topk_fast(d_x, n, 0, d_index, d_q, nq, d, k, nullptr, nullptr, d_workspace, workspace_bytes, (hipStream_t)stream, 1, d_lb);
-    // shapes without a two-phase path (small shards, d % 128 != 0, k > 1024, more queries than one launch chunk): no bound;
-    // ance_ip_topk_finish then simply runs the whole search
-    hipLaunchKernelGGL(fill_neg_inf_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_lb, nq);
-    return check_launch("ance_ip_topk_scan");
-}
-
-extern "C" int ance_ip_topk_finish(const float *d_x, int64_t n, int64_t row_base, const void *d_index, const float *d_q, int64_t nq, int d,
-                                   int k, const float *d_lb_global, float *d_out_d, int64_t *d_out_i, void *d_workspace,
-                                   size_t workspace_bytes, void *stream) {
-    if (!d_x || !d_q || !d_out_d || !d_out_i || !d_workspace || nq < 1 || n < 0 || k < 1) {
-        set_last_error("ance_ip_topk_finish: invalid argument");
-        return ANCE_E_INVALID;
-    }
-    if (two_phase_fast(d_x, d_index, d_q, n, nq, d, k, d_workspace))
-        return ip_topk_fast(d_x, n, row_base, d_index, d_q, nq, d, k, d_out_d, d_out_i, d_workspace, workspace_bytes, (hipStream_t)stream, 2,
-                            const_cast<float *>(d_lb_global));
-    return ance_ip_topk_indexed(d_x, n, row_base, d_index, d_q, nq, d, k, d_out_d, d_out_i, d_workspace, workspace_bytes, stream);
 }
 
 extern "C" size_t ance_topk_merge_workspace_bytes(int n_parts, int64_t nq, int k) {

@@ -930,23 +930,14 @@ struct RescoreParams {
     uint32_t nq;
     int d, k, S;
     EpsConst eps;
-    // two-phase search (ance_ip_topk_scan / _finish): BOUND_ONLY launches leave the k-th best approximate score of every list
-    // pair in thr_pair [n_qt * S][FQ] (-inf: fewer than k rows); the re-scoring launch of the finish phase takes one more lower
-    // bound per query, ext_thr [nq], in this shard's approximate-score units (NULL: none)
-    float *thr_pair;
-    const float *ext_thr;
 };
 constexpr int RS_CHUNK = 256;            // floats of a row staged per step
 constexpr int RS_STRIDE = RS_CHUNK + 4;  // floats between the staged pieces of consecutive rows
 inline size_t rescore_lds_bytes(int d) { return ((size_t)d + F_C / 2 + 64 * RS_STRIDE) * sizeof(float); }
 
-template <bool BOUND_ONLY>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) rescore_kernel(const RescoreParams P) {  // LDS allows 2 waves per CU
     extern __shared__ __attribute__((aligned(16))) float rs_smem[];
-    if (P.qstat->bad_image) {
-        if (BOUND_ONLY && threadIdx.x == 0) P.thr_pair[blockIdx.x] = -INFINITY;
-        return;
-    }
+    if (P.qstat->bad_image) return;
     const int l = threadIdx.x;
     const int d = P.d;
     float *qrow_lds = rs_smem;                                                   // d floats
@@ -958,16 +949,12 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
     const size_t ts = lid / FQ;  // qt * S + split
     const int split = (int)(ts % P.S);
     const uint32_t qg = (uint32_t)(ts / P.S) * FQ + ql;
-    if (qg >= P.nq) {
-        if (BOUND_ONLY && l == 0) P.thr_pair[lid] = -INFINITY;
-        return;
-    }
+    if (qg >= P.nq) return;
     const int n_c = P.cnt_g[lid];
     const u64 *cq = P.cand + lid * (size_t)F_C;
     u64 *dst = P.part + ((size_t)qg * P.S + split) * (size_t)P.k;
     const float *qsrc = P.q32 + (size_t)qg * d;
-    if (!BOUND_ONLY)
-        for (int k4 = l * 4; k4 < d; k4 += 256) *reinterpret_cast<f32x4 *>(qrow_lds + k4) = *reinterpret_cast<const f32x4 *>(qsrc + k4);
+    for (int k4 = l * 4; k4 < d; k4 += 256) *reinterpret_cast<f32x4 *>(qrow_lds + k4) = *reinterpret_cast<const f32x4 *>(qsrc + k4);
     const float eps2 = two_eps(P.eps, P.qnorm_c[qg], P.qnorm_o[qg], P.qstat, P.hdr);  // as in the filter kernel
     const u64 lt_mask = (1ull << l) - 1ull;
     u64 keys[F_NPL];
@@ -1014,19 +1001,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
             }
             if (ge >= P.k) T = t2;
         }
-        if (BOUND_ONLY) {
-            if (l == 0) P.thr_pair[lid] = T != 0u ? key_score((u64)T << 32) : -INFINITY;
-            return;
-        }
         if (T != 0u) thr_band = fmaxf(thr_band, key_score((u64)T << 32) - eps2);
-    } else if (BOUND_ONLY) {
-        if (l == 0) P.thr_pair[lid] = -INFINITY;
-        return;
-    }
-    if (BOUND_ONLY) return;
-    if (P.ext_thr) {  // rows that cannot be in the GLOBAL top-k (another shard's k-th best score is above anything they can reach)
-        const float e = P.ext_thr[qg];
-        if (e == e) thr_band = fmaxf(thr_band, e);
     }
     int n_band = 0;
 #pragma unroll
@@ -1088,64 +1063,6 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
     }
 }
 
-// ---- two-phase search: bounds that travel between shards ------------------------------------------------------------------
-// An approximate score of this shard is  s~ = q.(x - mu) +- eps : the shard mean mu differs from rank to rank, so a bound has to
-// travel in EXACT-score units.  Scan phase: lb[q] = (k-th best approximate score the filter kept for q) + q.mu - eps  <=  the
-// k-th best exact score of this shard  <=  the k-th best exact score of the whole corpus T*.  Finish phase, with Lb = the maximum
-// of lb over the shards: a row with  s~ < Lb - q.mu - eps  has an exact score  <= s~ + q.mu + eps < Lb <= T*  and cannot be in the
-// global top-k; the re-scoring drops it (ext_thr).  q.mu is accumulated in fp64 (at |q||mu| ~ 750 an fp32 dot is off by more
-// than eps); both conversions round toward -inf.  Queries whose lists overflowed, an image that is not trusted, eps = inf: no
-// bound (-inf), the query is answered as before.  One wave per query.
-__global__ void __launch_bounds__(256) lb_reduce_kernel(const float *q32, const float *mu, int d, uint32_t nq, int S, const float *thr_pair,
-                                                        const float *qnorm_c, const float *qnorm_o, const QueryStat *qs,
-                                                        const DedupHeader *H, EpsConst E, const FastCtl *ctl, const int *ovf_flag,
-                                                        double *qmu, float *lb) {
-    const uint32_t q = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int l = threadIdx.x & 63;
-    if (q >= nq) return;
-    double acc = 0.0;
-    for (int c = l; c < d; c += 64) acc += (double)q32[(size_t)q * d + c] * (double)mu[c];
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
-    float m = -INFINITY;
-    const size_t qt = q / FQ;
-    const int ql = (int)(q % FQ);
-    for (int sp = l; sp < S; sp += 64) m = fmaxf(m, thr_pair[(qt * S + sp) * FQ + ql]);
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
-    if (l == 0) {
-        const float eps2 = two_eps(E, qnorm_c[q], qnorm_o[q], qs, H);
-        const bool none = qs->bad_image || ctl->ovf_count > OVF_CAP || ovf_flag[q] != 0 || !(eps2 < 3.0e38f) || !(m > -3.0e38f);
-        qmu[q] = acc;
-        float v = -INFINITY;
-        if (!none) {
-            const double e = (double)m + acc - 0.5 * (double)eps2;
-            v = (float)e;
-            if ((double)v > e) v = nextafterf(v, -INFINITY);
-        }
-        lb[q] = v;
-    }
-}
-__global__ void __launch_bounds__(256) ext_thr_kernel(const float *lb_global, const double *qmu, uint32_t nq, const float *qnorm_c,
-                                                      const float *qnorm_o, const QueryStat *qs, const DedupHeader *H, EpsConst E,
-                                                      float *ext_thr) {
-    const uint32_t q = blockIdx.x * 256 + threadIdx.x;
-    if (q >= nq) return;
-    const float g = lb_global[q];
-    const float eps2 = two_eps(E, qnorm_c[q], qnorm_o[q], qs, H);
-    float v = -INFINITY;
-    if (g == g && g > -3.0e38f && eps2 < 3.0e38f && !qs->bad_image) {
-        const double e = (double)g - qmu[q] - 0.5 * (double)eps2;
-        v = (float)e;
-        if ((double)v > e) v = nextafterf(v, -INFINITY);
-    }
-    ext_thr[q] = v;
-}
-__global__ void __launch_bounds__(256) fill_f32_kernel(float *p, int64_t n, float v) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) p[i] = v;
-}
-
 // after the filter launch: turn the overflow list into the input of the per-query exact scan
 __global__ void __launch_bounds__(256) gather_overflow_kernel(FastCtl *ctl, const QueryStat *qs, const int *ovf_list, const float *q32,
                                                               int d, float *qfb, int *fb_slot) {
@@ -1178,7 +1095,6 @@ struct FastPlan {
     int S, Ws;
     int64_t qc;  // queries per launch
     size_t q2_bytes, qn_bytes, qctr_bytes, bias_bytes, cand_bytes, part_bytes, thr_bytes, cnt_bytes, flag_bytes, qfb_bytes, fbk_bytes, fb_bytes, fball_bytes;
-    size_t lb_bytes;  // two-phase search: thr_pair [qct * S][FQ] f32, q.mu [qc] f64, ext_thr [qc] f32
 };
 
 int env_int(const char *name, int dflt) {
@@ -1244,8 +1160,6 @@ bool make_fast_plan(int64_t n, int64_t nq, int d, int k, FastPlan *pl) {
     pl->thr_bytes = align_up((size_t)qct * S * FQ * sizeof(float) + (size_t)pl->qc * sizeof(int), 256);  // thr_g + fb_slot (0xFF fill)
     pl->cnt_bytes = align_up((size_t)qct * S * FQ * sizeof(int), 256);
     pl->flag_bytes = align_up(256 + (size_t)pl->qc * sizeof(int) + OVF_CAP * sizeof(int), 256);  // ctl + ovf_flag + ovf_list (0 fill)
-    pl->lb_bytes = align_up((size_t)qct * S * FQ * sizeof(float), 256) + align_up((size_t)pl->qc * sizeof(double), 256) +
-                   align_up((size_t)pl->qc * sizeof(float), 256);
     pl->qfb_bytes = align_up((size_t)OVF_CAP * d * sizeof(float), 256);
     pl->fbk_bytes = align_up((size_t)OVF_CAP * k * sizeof(u64), 256);
     const int64_t nqc = nq < pl->qc ? nq : pl->qc;
@@ -1256,7 +1170,7 @@ bool make_fast_plan(int64_t n, int64_t nq, int d, int k, FastPlan *pl) {
 
 size_t fast_search_bytes(const FastPlan &pl) {
     return 256 + pl.q2_bytes + pl.qn_bytes + pl.qctr_bytes + pl.bias_bytes + pl.part_bytes + pl.cand_bytes + pl.thr_bytes + pl.cnt_bytes + pl.flag_bytes + pl.qfb_bytes +
-           pl.fbk_bytes + pl.fb_bytes + pl.fball_bytes + pl.lb_bytes;
+           pl.fbk_bytes + pl.fb_bytes + pl.fball_bytes;
 }
 
 unsigned long long *g_fast_stamps = nullptr;
@@ -1320,24 +1234,12 @@ size_t ip_topk_fast_workspace_bytes(int64_t n, int64_t nq, int d, int k, bool wi
     return fast_search_bytes(pl) + (with_index ? ip_index_bytes(n, d) : 0);
 }
 
-int64_t ip_topk_fast_chunk_queries(int64_t n, int64_t nq, int d, int k) {
-    FastPlan pl;
-    return make_fast_plan(n, nq, d, k, &pl) ? pl.qc : 0;
-}
-
 // d_index: a search image built by ip_index_build for exactly (d_x, n, d), or NULL (then it is built inside the workspace)
-// phase 0: the whole search.  Two-phase search (one launch chunk per call, nq <= ip_topk_fast_chunk_queries): phase 1 = prepare +
-// filter + per-query lower bounds of this shard's k-th best exact score -> d_lb [nq]; phase 2 (same arguments, untouched
-// workspace) = re-scoring cut by d_lb = the maximum of those bounds over all shards (or NULL), overflow redo, finalize.
 int ip_topk_fast(const float *d_x, int64_t n, int64_t row_base, const void *d_index, const float *d_q, int64_t nq, int d, int k,
-                 float *d_out_d, int64_t *d_out_i, void *d_workspace, size_t workspace_bytes, hipStream_t st, int phase, float *d_lb) {
+                 float *d_out_d, int64_t *d_out_i, void *d_workspace, size_t workspace_bytes, hipStream_t st) {
     FastPlan pl;
     if (!make_fast_plan(n, nq, d, k, &pl)) {
         set_last_error("ip_topk_fast: shape not eligible");
-        return ANCE_E_INVALID;
-    }
-    if (phase != 0 && (nq > pl.qc || !d_index || (phase == 1 && !d_lb))) {
-        set_last_error("ip_topk_fast: a two-phase call takes one launch chunk (ance_ip_topk_scan_max_queries) and a built image");
         return ANCE_E_INVALID;
     }
     if (workspace_bytes < ip_topk_fast_workspace_bytes(n, nq, d, k, d_index == nullptr)) {
@@ -1362,10 +1264,6 @@ int ip_topk_fast(const float *d_x, int64_t n, int64_t row_base, const void *d_in
     u64 *fb_keys = reinterpret_cast<u64 *>(p); p += pl.fbk_bytes;
     void *fb_ws = p; p += pl.fb_bytes;
     void *fball_ws = p; p += pl.fball_bytes;
-    float *thr_pair = reinterpret_cast<float *>(p);
-    double *qmu = reinterpret_cast<double *>(p + align_up((size_t)(pl.qc / FQ) * pl.S * FQ * sizeof(float), 256));
-    float *ext_thr = reinterpret_cast<float *>(reinterpret_cast<char *>(qmu) + align_up((size_t)pl.qc * sizeof(double), 256));
-    p += pl.lb_bytes;
     if (!d_index) {
         void *own = p;
         const int rc = ip_index_build(d_x, n, d, own, ip_index_bytes(n, d), st);
@@ -1396,9 +1294,7 @@ int ip_topk_fast(const float *d_x, int64_t n, int64_t row_base, const void *d_in
             ok = ok && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)F_LDS_BYTES) == hipSuccess;
         if (!ok)
             return check_launch("ip_topk_fast attr");
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(rescore_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)rescore_lds_bytes(F_MAX_D)) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void *>(rescore_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(rescore_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)rescore_lds_bytes(F_MAX_D)) != hipSuccess)
             return check_launch("rescore attr");
         attr_mark(&attr_done);
@@ -1410,7 +1306,7 @@ int ip_topk_fast(const float *d_x, int64_t n, int64_t row_base, const void *d_in
     eps.abs_c = 1.25f * 5.9604645e-8f * sqrtf((float)d);
     eps.chain_o = 1.25f * d * 5.9604645e-8f;
     // ---- the mean query of this call and its per-row share of every score (skipped on the device when |mq| is small) ----
-    if (phase != 2) {
+    {
         const IndexLayout Li = index_layout(n, d);
         const char *ib = reinterpret_cast<const char *>(align_up((uintptr_t)d_index, 256));
         const int n_part_q = (int)(nq < 1024 ? nq : 1024);
@@ -1431,11 +1327,9 @@ int ip_topk_fast(const float *d_x, int64_t n, int64_t row_base, const void *d_in
 #endif
     for (int64_t q0 = 0; q0 < nq; q0 += pl.qc) {
         const int64_t nqc = (nq - q0) < pl.qc ? (nq - q0) : pl.qc;
-        if (phase != 2) {
-            (void)hipMemsetAsync(ff_area, 0xFF, pl.thr_bytes, st);
-            (void)hipMemsetAsync(zero_area, 0, pl.flag_bytes, st);
-        }
-        if (phase != 2) {
+        (void)hipMemsetAsync(ff_area, 0xFF, pl.thr_bytes, st);
+        (void)hipMemsetAsync(zero_area, 0, pl.flag_bytes, st);
+        {
             ProfScope ps(PC_PLAN, st);
             hipLaunchKernelGGL(round_rows_kernel, dim3((unsigned)((nqc + 3) / 4 < 8192 ? (nqc + 3) / 4 : 8192)), dim3(256), 0, st,
                                d_q + (size_t)q0 * d, nqc, d, mq, q2, qn, qn_o);
@@ -1459,7 +1353,7 @@ int ip_topk_fast(const float *d_x, int64_t n, int64_t row_base, const void *d_in
         const int gq = 32 / pl.S;
         const int groups = (P.n_qt + gq - 1) / gq;
         const unsigned blocks = (unsigned)((groups + 7) / 8 * 8) * 32u;
-        if (phase != 2) {
+        {
             ProfScope ps(PC_SCAN, st, 2.0 * (double)nqc * (double)n * (double)d);
 #ifdef ANCE_MEASURE  // the instrumented builds (per-workgroup time stamps, timing experiments) exist in the measurement library only
             if (stamps) {
@@ -1472,25 +1366,12 @@ int ip_topk_fast(const float *d_x, int64_t n, int64_t row_base, const void *d_in
                 hipLaunchKernelGGL((ip_topk_fast_kernel<false, true>), dim3(blocks), dim3(F_THREADS), F_LDS_BYTES, st, P);
             }
         }
-        RescoreParams R;
-        R.q32 = P.q32; R.x32 = d_x; R.qnorm_c = qn; R.qnorm_o = qn_o; R.qstat = qstat; R.hdr = H; R.live2row = P.live2row; R.cand = cand; R.cnt_g = cnt_g; R.thr_g = thr_g;
-        R.part = part; R.nq = P.nq; R.d = d; R.k = k; R.S = pl.S; R.eps = eps; R.thr_pair = thr_pair; R.ext_thr = nullptr;
-        if (phase == 1) {  // this shard's bounds; everything the finish phase needs stays in the workspace
-            ProfScope ps(PC_RESCORE, st);
-            hipLaunchKernelGGL(rescore_kernel<true>, dim3((unsigned)(P.n_qt * pl.S * FQ)), dim3(64), rescore_lds_bytes(d), st, R);
-            hipLaunchKernelGGL(lb_reduce_kernel, dim3((unsigned)((nqc + 3) / 4)), dim3(256), 0, st, P.q32, reinterpret_cast<const float *>(ibase + L.mu_off),
-                               d, P.nq, pl.S, (const float *)thr_pair, (const float *)qn, (const float *)qn_o, (const QueryStat *)qstat, H, eps,
-                               (const FastCtl *)ctl, (const int *)ovf_flag, qmu, d_lb);
-            return check_launch("ip_topk_fast scan");
-        }
         {
+            RescoreParams R;
+            R.q32 = P.q32; R.x32 = d_x; R.qnorm_c = qn; R.qnorm_o = qn_o; R.qstat = qstat; R.hdr = H; R.live2row = P.live2row; R.cand = cand; R.cnt_g = cnt_g; R.thr_g = thr_g;
+            R.part = part; R.nq = P.nq; R.d = d; R.k = k; R.S = pl.S; R.eps = eps;
             ProfScope ps(PC_RESCORE, st);
-            if (phase == 2 && d_lb) {
-                hipLaunchKernelGGL(ext_thr_kernel, dim3((unsigned)((nqc + 255) / 256)), dim3(256), 0, st, (const float *)d_lb, (const double *)qmu, P.nq,
-                                   (const float *)qn, (const float *)qn_o, (const QueryStat *)qstat, H, eps, ext_thr);
-                R.ext_thr = ext_thr;
-            }
-            hipLaunchKernelGGL(rescore_kernel<false>, dim3((unsigned)(P.n_qt * pl.S * FQ)), dim3(64), rescore_lds_bytes(d), st, R);
+            hipLaunchKernelGGL(rescore_kernel, dim3((unsigned)(P.n_qt * pl.S * FQ)), dim3(64), rescore_lds_bytes(d), st, R);
         }
         // queries whose buffers overflowed: redone by the exact scan, one by one (<= OVF_CAP) or as a whole chunk
         hipLaunchKernelGGL(gather_overflow_kernel, dim3(OVF_CAP), dim3(256), 0, st, ctl, qstat, ovf_list, d_q + (size_t)q0 * d, d, qfb, fb_slot);

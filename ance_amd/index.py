@@ -170,58 +170,6 @@ class FlatIPIndex:
         return D, I
 
 
-    # -- two-phase search of a shard (scan -> bounds travel between the shards -> finish) -------------------
-    def scan_max_queries(self, nq, k):
-        """Queries one scan / finish call pair takes for this shard (0: no two-phase path for this shape)."""
-        x = self._matrix()
-        return int(_lib.lib().ance_ip_topk_scan_max_queries(x.shape[0], int(nq), self.dp, int(k)))
-
-    def _two_phase_args(self, qd, k):
-        import torch
-        L = _lib.lib()
-        x = self._matrix()
-        n, nq = x.shape[0], qd.shape[0]
-        if not 1 <= k <= self.MAX_K:
-            raise ValueError("k must be in [1, %d]" % self.MAX_K)
-        img = self._search_image(L, x)
-        need = L.ance_ip_topk_indexed_workspace_bytes(n, nq, self.dp, k)
-        if need == 0:
-            raise _lib.AnceLibraryError("ance_ip_topk: unsupported (n=%d, nq=%d, k=%d)" % (n, nq, k))
-        if self._ws is None or self._ws.numel() < need:
-            self._ws = None
-            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
-        return L, x, n, nq, img
-
-    def scan_device(self, qd, k):
-        """Scan phase (``ance_ip_topk_scan``): CUDA fp32 [nq] lower bounds of this shard's k-th best exact score (-inf: none).
-        The workspace keeps the state ``finish_device`` continues from: nothing else may search this index in between."""
-        import torch
-        L, x, n, nq, img = self._two_phase_args(qd, int(k))
-        lb = torch.empty((nq,), dtype=torch.float32, device=self.device)
-        with torch.cuda.device(self.device):
-            rc = L.ance_ip_topk_scan(ctypes.c_void_p(x.data_ptr()), n, ctypes.c_void_p(img.data_ptr()) if img is not None else None,
-                                     ctypes.c_void_p(qd.data_ptr()), nq, self.dp, int(k), ctypes.c_void_p(lb.data_ptr()),
-                                     ctypes.c_void_p(self._ws.data_ptr()), self._ws.numel(), _lib.current_stream_ptr())
-        _lib.check(rc, "ance_ip_topk_scan")
-        return lb
-
-    def finish_device(self, qd, k, lb_global):
-        """Finish phase (``ance_ip_topk_finish``) with ``lb_global`` = the element-wise maximum of every shard's ``scan_device``
-        result (or None).  Returns (D, I); lists may be shorter than k ((-FLT_MAX, -1) padding)."""
-        import torch
-        L, x, n, nq, img = self._two_phase_args(qd, int(k))
-        D = torch.empty((nq, k), dtype=torch.float32, device=self.device)
-        I = torch.empty((nq, k), dtype=torch.int64, device=self.device)
-        with torch.cuda.device(self.device):
-            rc = L.ance_ip_topk_finish(ctypes.c_void_p(x.data_ptr()), n, self.row_base,
-                                       ctypes.c_void_p(img.data_ptr()) if img is not None else None, ctypes.c_void_p(qd.data_ptr()), nq,
-                                       self.dp, int(k), ctypes.c_void_p(lb_global.data_ptr()) if lb_global is not None else None,
-                                       ctypes.c_void_p(D.data_ptr()), ctypes.c_void_p(I.data_ptr()), ctypes.c_void_p(self._ws.data_ptr()),
-                                       self._ws.numel(), _lib.current_stream_ptr())
-        _lib.check(rc, "ance_ip_topk_finish")
-        return D, I
-
-
 def topk_merge_device(D_parts, I_parts):
     """Merge canonical lists [P, nq, k] (CUDA tensors) -> ([nq, k], [nq, k]) via ``ance_topk_merge``."""
     import torch

@@ -38,7 +38,7 @@ extern "C" {
 #define ANCE_E_LAUNCH (-3)    /* HIP reported a launch error */
 #define ANCE_E_NOMEM (-4)
 
-#define ANCE_ABI_VERSION 3  /* 3: + ance_nll_forward, ance_ip_topk_scan / _finish, ance_search_bad_image_calls, ance_debug_gemm_split; split encoder mode */
+#define ANCE_ABI_VERSION 3  /* 3: + ance_nll_forward, ance_search_bad_image_calls, ance_debug_gemm_split; split encoder mode */
 int ance_abi_version(void);
 /* last HIP error string seen by this library on the calling thread ("" if none) */
 const char *ance_last_error(void);
@@ -244,26 +244,6 @@ int ance_encode_ids(AnceEncoder *enc, const int32_t *d_ids, int64_t ld_ids, cons
  */
 int ance_debug_gemm(int ablate, int epi, const void *d_a_f16, const void *d_b_f16, int M, int N, int K,
                     const float *d_bias, void *d_out, const float *d_res32, void *stream);
-
-/* Two-phase search for a corpus sharded over several GPUs (the reference's own shard-search-then-merge is
- * utils/eval_mrr.py:137-183).  ance_ip_topk_indexed re-scores, on every shard, the ~k + 66 rows per query that could be in the
- * SHARD's top-k; only ~k / G of them can be in the global one.  Between a scan phase and a finish phase the shards exchange one
- * float per query:
- *   ance_ip_topk_scan    prepare + filter on this shard; d_lb[q] = a lower bound of this shard's k-th best exact score
- *                        (-inf where there is none: fewer than k rows, overflowed lists, shapes without a fast path)
- *   (caller)             d_lb_global = element-wise MAX of d_lb over all shards -- one all_reduce of nq floats
- *   ance_ip_topk_finish  same arguments, same untouched workspace; exact re-scoring of the rows that can still be in the GLOBAL
- *                        top-k, finalize.  Lists may hold fewer than k entries ((-FLT_MAX, -1) padding); merged with
- *                        ance_topk_merge over the shards they give bit-identical results to a search of the whole corpus.
- * One launch chunk per call pair: nq <= ance_ip_topk_scan_max_queries(n, nq, d, k) (0: this shape has no two-phase path; the
- * pair still works -- scan returns -inf, finish runs the whole search).  Workspace: ance_ip_topk_indexed_workspace_bytes.
- * d_lb_global may be NULL (no exchange: same results as ance_ip_topk_indexed). */
-int64_t ance_ip_topk_scan_max_queries(int64_t n, int64_t nq, int d, int k);
-int ance_ip_topk_scan(const float *d_x, int64_t n, const void *d_index, const float *d_q, int64_t nq, int d, int k, float *d_lb,
-                      void *d_workspace, size_t workspace_bytes, void *stream);
-int ance_ip_topk_finish(const float *d_x, int64_t n, int64_t row_base, const void *d_index, const float *d_q, int64_t nq, int d, int k,
-                        const float *d_lb_global, float *d_out_d, int64_t *d_out_i, void *d_workspace, size_t workspace_bytes,
-                        void *stream);
 
 /* Diagnostic: the number of ance_ip_topk_indexed launch chunks on the current device whose search image did not carry the stamp
  * of the matrix searched (moved / copied rows, a view at another address, a buffer that was never built).  Such calls are

@@ -1,3 +1,4 @@
+"""NOTE: measures the two-phase search API of commit 3758d29 (reverted: see DESIGN.md section 9); check that commit out to re-run."""
 """What the threshold exchange between shards buys at the shard size of an 8-GPU job, measured on ONE GPU: the 8,841,823-row
 corpus of the bench is generated shard by shard (1,105,228 rows each), every shard is scanned (ance_ip_topk_scan) for the same
 32,768 queries -- exactly the bounds seven other ranks would send --, and shard 0's finish phase is timed with their maximum

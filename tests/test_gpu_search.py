@@ -627,56 +627,3 @@ def test_image_of_another_matrix_is_not_trusted():
     _lib.check(rc, "ance_ip_topk_indexed")
     torch.cuda.synchronize()
     assert np.array_equal(I.cpu().numpy(), Io) and np.array_equal(D.cpu().numpy(), Do)
-
-
-@pytest.mark.parametrize("kind", ["ln", "encoder_like", "duplicates"])
-def test_two_phase_search_over_three_shards_is_the_search_of_the_whole(kind):
-    """ance_ip_topk_scan / ance_ip_topk_finish (sharded corpora): every shard scans, the shards exchange the element-wise
-    maximum of their lower bounds (here: a torch.maximum), every shard re-scores only what can still be in the GLOBAL top-k,
-    and the merged lists are bit-identical -- ids and scores -- to the oracle's search of the whole matrix.  Encoder-like rows
-    make the shard means large and different (the bound has to travel in exact-score units), the duplicate class is collapsed
-    in one shard's image and absent from the others."""
-    import torch
-    from ance_amd.index import FlatIPIndex, topk_merge_device
-    from oracle import search_ref, synth
-    rng = np.random.default_rng(71)
-    n, nq, k = 60000, 300, 100
-    if kind == "encoder_like":
-        x, c = _encoder_like(rng, n)
-        x[20000:] += 0.05 * rng.standard_normal(768).astype(np.float32)   # the shards do not share one mean
-        q = (c[None, :] + 0.12 * rng.standard_normal((nq, 768))).astype(np.float32)
-    else:
-        x, q = synth.ln_rows(rng, n), synth.ln_rows(rng, nq)
-        if kind == "duplicates":
-            x[30000:36000] = x[123]      # a heavy class inside the second shard, its first member in the first
-            q[:20] = x[123] + 0.01 * rng.standard_normal((20, 768)).astype(np.float32)
-    bounds = [0, 25000, 45000, n]
-    xd, qd = torch.from_numpy(x).cuda(), torch.from_numpy(q).cuda()
-    shards = []
-    for s in range(3):
-        idx = FlatIPIndex(768, row_base=bounds[s])
-        idx.add(xd[bounds[s]:bounds[s + 1]])
-        assert idx.scan_max_queries(nq, k) >= nq
-        shards.append(idx)
-    # scan -> max -> finish, one shard after the other (each index keeps its own workspace between its two calls)
-    lbs = [idx.scan_device(qd, k) for idx in shards]
-    lb = torch.stack(lbs).max(dim=0).values
-    assert bool(torch.isfinite(lb).all())
-    parts = [idx.finish_device(qd, k, lb) for idx in shards]
-    D, I = topk_merge_device(torch.stack([p[0] for p in parts]), torch.stack([p[1] for p in parts]))
-    Do, Io = search_ref.flat_ip_topk_chain(x, q, k)
-    assert np.array_equal(I.cpu().numpy(), Io) and np.array_equal(D.cpu().numpy(), Do)
-    kept = sum(int((p[1] >= 0).sum()) for p in parts)
-    assert kept < 0.75 * 3 * nq * k, kept          # the exchange really cuts: well under k entries per shard and query survive
-    # without bounds the pair is the plain search of the shard
-    for s, idx in enumerate(shards):
-        idx.scan_device(qd, k)
-        D1, I1 = idx.finish_device(qd, k, None)
-        D2, I2 = idx.search_device(qd, k)
-        assert torch.equal(I1, I2) and torch.equal(D1, D2)
-    # a bound that is too LOW only costs work; one shard alone (its own bound) still answers its own top-k exactly
-    idx = shards[0]
-    own = idx.scan_device(qd, k)
-    D3, I3 = idx.finish_device(qd, k, own)
-    D4, I4 = idx.search_device(qd, k)
-    assert torch.equal(I3, I4) and torch.equal(D3, D4)
