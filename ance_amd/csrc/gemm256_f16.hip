@@ -291,96 +291,6 @@ __global__ void __launch_bounds__(G256_THREADS, 2) gemm256_split_kernel(const Ge
     gemm256_epilogue_split<EPI>(G, acc, smem_f, m0, n0, w, l);
 }
 
-// ---- EXPERIMENT (round 4): 128 x 256 tile, 4 waves, TWO workgroups per CU -----------------------------------
-// The structure the verdict asked to be measured: half the M extent per workgroup, a BK = 32 three-stage LDS ring (72 KiB), so
-// that two workgroups share a CU and one's epilogue / prologue runs under the other's MFMAs; no intra-workgroup ping-pong -- the
-// two resident workgroups put two waves on every SIMD and the hardware interleaves them.  One barrier per 32-deep K step.  Staging
-// is LDS-DMA with the XOR swizzle on the source side as in pipe256.h; rows are 64 bytes here, so the swizzle is (row >> 2) & 3
-// (the 16 rows a quarter-wave's ds_read_b128 touches must land in 16 different 16-byte bank groups).  Same MFMA orientation and
-// accumulator layout as the 256 x 256 kernel (a wave owns 128 m x 64 n), so gemm256_epilogue runs unchanged with wm = 0.
-// Non-folded epilogues only (EPI_QK / GELU / RES32 / VT: the ANCE_LN_FOLD=0 form of the encoder) -- the 28 KB parameter block of
-// the folded ones does not fit next to two 72 KiB rings.  ANCE_GEMM_TILE128=1 selects it; numbers in DESIGN.md section 9.
-constexpr int T128_STAGE_HALVES = (128 + 256) * 32;                 // A 8 KiB + B 16 KiB
-constexpr size_t T128_LDS_BYTES = (size_t)3 * T128_STAGE_HALVES * 2;  // 72 KiB
-
-template <int EPI>
-__global__ void __launch_bounds__(256, 2) gemm128_f16_kernel(const GemmArgs G) {
-    extern __shared__ __attribute__((aligned(16))) float smem_f[];
-    _Float16 *smem = reinterpret_cast<_Float16 *>(smem_f);
-    const int NT = G.N / 256, MT = G.M / 128;
-    const int b = blockIdx.x, xcd = b & 7, jx = b >> 3;
-    int mt, nt;
-    if (MT >= NT) { mt = (jx / NT) * 8 + xcd; nt = jx % NT; } else { nt = (jx / MT) * 8 + xcd; mt = jx % MT; }
-    if (mt >= MT || nt >= NT) return;
-    const int m0 = mt * 128, n0 = nt * 256;
-    const int tid = threadIdx.x;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int l = tid & 63, g = l >> 5, i = l & 31;
-    f32x16 acc[2][4];
-#pragma unroll
-    for (int x = 0; x < 2; ++x)
-#pragma unroll
-        for (int y = 0; y < 4; ++y) acc[x][y] = f32x16{0};
-    // staging: 24 pieces of 1 KiB per stage (8 A, 16 B), wave w issues pieces w, w + 4, ...: 2 A + 4 B.  Piece p covers rows
-    // 16 p' .. 16 p' + 15 of its operand tile; lane L fills slot L & 3 of row L >> 2 and reads source chunk slot ^ swz(row).
-    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16 *>(G.A + (size_t)m0 * G.lda), 0, (int)(128u * (uint32_t)G.lda * 2u), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16 *>(G.B + (size_t)n0 * G.ldb), 0, (int)(256u * (uint32_t)G.ldb * 2u), 0x00020000);
-    uint32_t voffA[2], voffB[4];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int row = (w + 4 * j) * 16 + (l >> 2);
-        voffA[j] = (uint32_t)(row * G.lda + (((l & 3) ^ ((row >> 2) & 3)) * 8)) * 2u;
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int row = (w + 4 * j) * 16 + (l >> 2);
-        voffB[j] = (uint32_t)(row * G.ldb + (((l & 3) ^ ((row >> 2) & 3)) * 8)) * 2u;
-    }
-    auto stage = [&](int t) {
-        _Float16 *sa = smem + (t % 3) * T128_STAGE_HALVES, *sb = sa + 128 * 32;
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (pipe_lds_t *)(sa + (w + 4 * j) * 512), 16, voffA[j], t * 64, 0, 0);
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (pipe_lds_t *)(sb + (w + 4 * j) * 512), 16, voffB[j], t * 64, 0, 0);
-    };
-    // fragment offsets (halves) inside a stage: row * 32 + ((ks * 2 + g) ^ swz(row)) * 8; swz depends on i only (row offsets are
-    // multiples of 32 rows = 8 swizzle periods)
-    const int sw = (i >> 2) & 3;
-    int kx[2];
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) kx[ks] = ((ks * 2 + g) ^ sw) * 8;
-    const int rowB = (w * 64 + i) * 32;  // n rows of this wave (x adds 32 rows)
-    const int rowA = i * 32;             // m rows (y adds 32 rows)
-    const int NK = G.K / 32;
-    stage(0);
-    if (NK > 1) stage(1);
-    for (int t = 0; t < NK; ++t) {
-        if (t + 1 < NK) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();  // stage t is published; every wave is done reading stage t - 1, whose buffer stage t + 2 takes
-        if (t + 2 < NK) stage(t + 2);
-        const _Float16 *sa = smem + (t % 3) * T128_STAGE_HALVES, *sb = sa + 128 * 32;
-        f16x8 fb[2][2], fa[4][2];
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-#pragma unroll
-            for (int x = 0; x < 2; ++x) fb[x][ks] = *reinterpret_cast<const f16x8 *>(sb + rowB + x * 32 * 32 + kx[ks]);
-#pragma unroll
-            for (int y = 0; y < 4; ++y) fa[y][ks] = *reinterpret_cast<const f16x8 *>(sa + rowA + y * 32 * 32 + kx[ks]);
-        }
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int x = 0; x < 2; ++x)
-#pragma unroll
-                for (int y = 0; y < 4; ++y) acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[x][ks], fa[y][ks], acc[x][y], 0, 0, 0);
-    }
-    __syncthreads();  // the epilogue's slabs reuse the ring
-    gemm256_epilogue<EPI, true>(G, acc, smem_f, m0, n0, w, l);
-}
-
 template <int EPI, bool ABLATE>
 __global__ void __launch_bounds__(G256_THREADS, 2) gemm256_f16_kernel(const GemmArgs G) {
     extern __shared__ __attribute__((aligned(16))) float smem_f[];
@@ -476,25 +386,6 @@ int launch256(int epi, const GemmArgs &G, hipStream_t st) {
         use_desc = (e && atoi(e) == 0) ? 0 : 1;
     }
     const bool desc = !ABLATE && use_desc;
-    static int tile128 = -1;
-    if (tile128 < 0) {
-        const char *e = getenv("ANCE_GEMM_TILE128");
-        tile128 = (e && atoi(e) == 1) ? 1 : 0;
-    }
-    if (!ABLATE && tile128 && epi < EPI_RESLN && G.M % 128 == 0 && G.K % 32 == 0 && G.K >= 64 && G.n_split == 0) {
-        void (*k8)(const GemmArgs) = epi == EPI_QK ? gemm128_f16_kernel<EPI_QK> : epi == EPI_GELU ? gemm128_f16_kernel<EPI_GELU>
-                                     : epi == EPI_RES32 ? gemm128_f16_kernel<EPI_RES32> : gemm128_f16_kernel<EPI_VT>;
-        static unsigned long long attr128[4] = {0, 0, 0, 0};
-        if (attr_needed(&attr128[epi])) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void *>(k8), hipFuncAttributeMaxDynamicSharedMemorySize, (int)T128_LDS_BYTES) != hipSuccess)
-                return check_launch("gemm128 attr");
-            attr_mark(&attr128[epi]);
-        }
-        const int MT8 = G.M / 128, NT8 = G.N / 256;
-        const unsigned blocks8 = MT8 >= NT8 ? (unsigned)((MT8 + 7) / 8 * 8) * (unsigned)NT8 : (unsigned)((NT8 + 7) / 8 * 8) * (unsigned)MT8;
-        hipLaunchKernelGGL(k8, dim3(blocks8), dim3(256), T128_LDS_BYTES, st, G);
-        return ANCE_OK;
-    }
     switch (epi) {
         case EPI_QK: k = desc ? gemm256_f16_desc_kernel<EPI_QK> : gemm256_f16_kernel<EPI_QK, ABLATE>; break;
         case EPI_GELU: k = desc ? gemm256_f16_desc_kernel<EPI_GELU> : gemm256_f16_kernel<EPI_GELU, ABLATE>; break;
