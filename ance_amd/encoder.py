@@ -55,6 +55,29 @@ def count_layers(state_dict, prefix):
     return n
 
 
+import contextlib
+
+
+@contextlib.contextmanager
+def _precision_env(env):
+    """The library reads the encoder mode from the environment when a handle is created (include/ance_amd.h): set exactly
+    ``env`` (a dict, or None = leave the environment as it is) for the duration of the create call.  One host thread per GPU
+    process, like the rest of the binding."""
+    if env is None:
+        yield
+        return
+    keys = ("ANCE_ENCODER_SPLIT", "ANCE_ENCODER_PRECISE")
+    saved = {k: os.environ.pop(k, None) for k in keys}
+    os.environ.update(env)
+    try:
+        yield
+    finally:
+        for k in keys:
+            os.environ.pop(k, None)
+            if saved[k] is not None:
+                os.environ[k] = saved[k]
+
+
 class Encoder:
     """One transformer tower + (optional) ANCE head resident in HBM."""
 
@@ -67,20 +90,12 @@ class Encoder:
         operands (the audit path, ~9 x slower).  The library reads the mode when the handle is created."""
         import torch
         L = _lib.lib()
-        if precision is not None:
-            if precision not in self.PRECISIONS:
-                raise ValueError("precision must be one of %s" % sorted(self.PRECISIONS))
-            saved = {k: os.environ.pop(k, None) for k in ("ANCE_ENCODER_SPLIT", "ANCE_ENCODER_PRECISE")}
-            os.environ.update(self.PRECISIONS[precision])
-            try:
-                self.__init__(state_dict, arch, prefix, has_head, pad_token_id, ln_eps, max_seq_len, max_tokens, device, None)
-            finally:
-                for k in ("ANCE_ENCODER_SPLIT", "ANCE_ENCODER_PRECISE"):
-                    os.environ.pop(k, None)
-                    if saved[k] is not None:
-                        os.environ[k] = saved[k]
-            self.precision = precision
-            return
+        if precision is not None and precision not in self.PRECISIONS:
+            raise ValueError("precision must be one of %s" % sorted(self.PRECISIONS))
+        with _precision_env(self.PRECISIONS.get(precision)):
+            self._create(L, torch, state_dict, arch, prefix, has_head, pad_token_id, ln_eps, max_seq_len, max_tokens, device)
+
+    def _create(self, L, torch, state_dict, arch, prefix, has_head, pad_token_id, ln_eps, max_seq_len, max_tokens, device):
         self.precision = "fp32" if os.environ.get("ANCE_ENCODER_PRECISE", "")[:1] == "1" else \
             ("split" if os.environ.get("ANCE_ENCODER_SPLIT", "")[:1] == "1" else "fp16")
         self.device = torch.device(device if device is not None else "cuda")
