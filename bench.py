@@ -524,7 +524,9 @@ def main():
             # ---- the two fp32-grade modes beside the default, as first-class measurements: the same block, the same K
             # steps, their own roofline (single-stream pass with the library's HIP events), and how far the default's
             # fp16-operand embeddings are from each on the same records (the stated tolerance, measured live)
-            if not a.skip_precise:
+            # (single-GPU runs only: the multi-GPU runs are the driver's scaling curve of `value`, and the audit path would
+            # double their length)
+            if not a.skip_precise and world == 1:
                 enc.encode_records(rec_d, h_lens=lens, out=emb)
                 torch.cuda.synchronize()
                 emb_default = emb.clone()
