@@ -66,6 +66,8 @@ def parse():
     p.add_argument("--full-queries", type=int, default=N_TRAIN_QUERIES)
     p.add_argument("--full-dev-queries", type=int, default=6980)
     p.add_argument("--negative-sample", type=int, default=20)
+    p.add_argument("--encoder-precision", type=str, default=None, choices=["fp16", "split", "fp32"],
+                   help="--full only: the encoder arithmetic of the refresh (ance_amd.ann_data_gen --encoder_precision)")
     return p.parse_args()
 
 
@@ -136,7 +138,7 @@ def full_refresh(a):
     args = types.SimpleNamespace(data_dir=data, output_dir=outd, cache_dir=outd, inference=False, topk_training=a.topk,
                                  negative_sample=a.negative_sample, ann_chunk_factor=1, ann_measure_topk_mrr=False,
                                  model_type="rdot_nll", max_seq_length=a.seq_len, max_query_length=64, device=dev,
-                                 max_tokens=a.max_tokens, timings=timings)
+                                 max_tokens=a.max_tokens, timings=timings, encoder_precision=a.encoder_precision)
     import logging
     import random
     logging.basicConfig(format="%(asctime)s %(name)s %(message)s", level=logging.INFO, stream=sys.stderr)
@@ -152,8 +154,10 @@ def full_refresh(a):
     if rank == 0:
         lines = sum(1 for _ in open(os.path.join(outd, "ann_training_data_0")))
         enc_s = timings.get("encode_passages", 0.0)
+        mode = a.encoder_precision or ("fp32" if os.environ.get("ANCE_ENCODER_PRECISE", "")[:1] == "1" else
+                                       "split" if os.environ.get("ANCE_ENCODER_SPLIT", "")[:1] == "1" else "fp16")
         out = {"metric": "full_refresh_seconds", "value": wall, "unit": "s", "n_gpus": world, "higher_is_better": False,
-               "dtype": "f16", "data": "synthetic",
+               "dtype": {"fp16": "f16", "split": "f16 pairs (fp32-grade)", "fp32": "f32"}[mode], "encoder_precision": mode, "data": "synthetic",
                "config": {"workload": "one ANN refresh: %d passages (seq_len %d, streamed from %s) + %d train queries "
                                       "(ann_chunk_factor 1) + %d dev queries, top-%d, %d negatives, roberta-base rdot_nll "
                                       "random init" % (a.n_passages, a.seq_len, d, a.full_queries, a.full_dev_queries, a.topk,

@@ -164,6 +164,30 @@ def test_cli_flags_match_reference_names():
 
 
 # ---- native host stage (csrc/host_postsearch.hip) ------------------------------------------------
+def test_encoder_precision_flag():
+    """The one added flag: --encoder_precision {fp16, split, fp32} (default: whatever the environment says)."""
+    from ance_amd import ann_data_gen as adg
+    base = ["--data_dir", "d", "--training_dir", "t", "--init_model_dir", "i", "--model_type", "rdot_nll", "--output_dir", "o",
+            "--cache_dir", "c"]
+    assert adg.get_arguments(base).encoder_precision is None
+    assert adg.get_arguments(base + ["--encoder_precision", "split"]).encoder_precision == "split"
+    with pytest.raises(SystemExit):
+        adg.get_arguments(base + ["--encoder_precision", "bf16"])
+
+
+def test_precision_env_context_restores_the_environment(monkeypatch):
+    from ance_amd.encoder import Encoder, _precision_env
+    monkeypatch.setenv("ANCE_ENCODER_PRECISE", "1")
+    monkeypatch.delenv("ANCE_ENCODER_SPLIT", raising=False)
+    with _precision_env(Encoder.PRECISIONS["split"]):
+        assert os.environ.get("ANCE_ENCODER_SPLIT") == "1" and "ANCE_ENCODER_PRECISE" not in os.environ
+    assert os.environ.get("ANCE_ENCODER_PRECISE") == "1" and "ANCE_ENCODER_SPLIT" not in os.environ
+    with _precision_env(Encoder.PRECISIONS["fp16"]):
+        assert "ANCE_ENCODER_PRECISE" not in os.environ and "ANCE_ENCODER_SPLIT" not in os.environ
+    with _precision_env(None):
+        assert os.environ.get("ANCE_ENCODER_PRECISE") == "1"
+
+
 def test_native_shuffle_continues_cpython_stream():
     for n in (0, 1, 2, 3, 7, 200, 1000, 4097, 100003):
         random.seed(1000 + n)
