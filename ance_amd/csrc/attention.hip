@@ -21,6 +21,7 @@
 // 126-148 us per launch at the bench shape against 117 us for this kernel: the launch is bound by the dependent
 // MFMA -> softmax -> MFMA chain inside each wave, which only residency (waves per SIMD) hides, not by the staging latency.
 #include <stdlib.h>
+#include <type_traits>
 
 #include "common.h"
 #include "attention.h"
@@ -294,41 +295,53 @@ __global__ void __launch_bounds__(64 * NW, 2) attention_split_kernel(const float
     const int ld = 3 * n_heads * HD;
     constexpr float SC = 2048.0f, SI = 1.0f / 2048.0f;
     // ---- stage K (rows = keys) and V^T (rows = head dims) of keys [k0, k0 + kc), split on the way; keys >= T are zeros ----
-    auto stage = [&](int k0) {
-        for (int e = tid; e < kc * 8; e += NT) {
-            const int kl_ = e >> 3, ch = e & 7, key = k0 + kl_;
-            f32x4 k0v = {0.f, 0.f, 0.f, 0.f}, k1v = k0v, v0 = k0v, v1 = k0v;
-            if (key < T) {
-                const float *kp = qkv + (size_t)(tok0 + key) * ld + n_heads * HD + h * HD + ch * 8;
-                k0v = *reinterpret_cast<const f32x4 *>(kp);
-                k1v = *reinterpret_cast<const f32x4 *>(kp + 4);
-                v0 = *reinterpret_cast<const f32x4 *>(kp + n_heads * HD);
-                v1 = *reinterpret_cast<const f32x4 *>(kp + n_heads * HD + 4);
-            }
-            const f16x4 a0 = cvt_f16x4_pinned(k0v), a1 = cvt_f16x4_pinned(k1v), b0 = cvt_f16x4_pinned(v0), b1 = cvt_f16x4_pinned(v1);
-            f16x8 kh, kl;
+    // UNR rounds of loads are issued before the first one is consumed: a sequence's K / V panel then costs one HBM latency, not
+    // one per round (4 rounds at 128 keys).  The chunked path (T > 256) stages under live accumulators and keeps UNR = 1.
+    auto stage = [&](int k0, auto unr_tag) {
+        constexpr int UNR = decltype(unr_tag)::value;
+        for (int e0 = tid; e0 < kc * 8; e0 += UNR * NT) {
+            f32x4 kv[UNR][4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                kh[j] = a0[j]; kh[4 + j] = a1[j];
-                kl[j] = (_Float16)((k0v[j] - (float)a0[j]) * SC);
-                kl[4 + j] = (_Float16)((k1v[j] - (float)a1[j]) * SC);
-            }
-            *reinterpret_cast<f16x8 *>(Kh + kl_ * HD + kswz(kl_, ch) * 8) = kh;
-            *reinterpret_cast<f16x8 *>(Kl + kl_ * HD + kswz(kl_, ch) * 8) = kl;
+            for (int it = 0; it < UNR; ++it) {
+                const int e = e0 + it * NT;
+                const int kl_ = e >> 3, ch = e & 7, key = k0 + kl_;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                Vh[(ch * 8 + j) * vld + kl_] = b0[j];
-                Vh[(ch * 8 + 4 + j) * vld + kl_] = b1[j];
-                Vl[(ch * 8 + j) * vld + kl_] = (_Float16)((v0[j] - (float)b0[j]) * SC);
-                Vl[(ch * 8 + 4 + j) * vld + kl_] = (_Float16)((v1[j] - (float)b1[j]) * SC);
+                for (int q = 0; q < 4; ++q) kv[it][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (e < kc * 8 && key < T) {
+                    const float *kp = qkv + (size_t)(tok0 + key) * ld + n_heads * HD + h * HD + ch * 8;
+                    kv[it][0] = *reinterpret_cast<const f32x4 *>(kp);
+                    kv[it][1] = *reinterpret_cast<const f32x4 *>(kp + 4);
+                    kv[it][2] = *reinterpret_cast<const f32x4 *>(kp + n_heads * HD);
+                    kv[it][3] = *reinterpret_cast<const f32x4 *>(kp + n_heads * HD + 4);
+                }
+            }
+#pragma unroll
+            for (int it = 0; it < UNR; ++it) {
+                const int e = e0 + it * NT;
+                if (e >= kc * 8) break;
+                const int kl_ = e >> 3, ch = e & 7;
+                const f32x4 k0v = kv[it][0], k1v = kv[it][1], v0 = kv[it][2], v1 = kv[it][3];
+                const f16x4 a0 = cvt_f16x4_pinned(k0v), a1 = cvt_f16x4_pinned(k1v), b0 = cvt_f16x4_pinned(v0), b1 = cvt_f16x4_pinned(v1);
+                f16x8 kh, kl;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    kh[j] = a0[j]; kh[4 + j] = a1[j];
+                    kl[j] = (_Float16)((k0v[j] - (float)a0[j]) * SC);
+                    kl[4 + j] = (_Float16)((k1v[j] - (float)a1[j]) * SC);
+                }
+                *reinterpret_cast<f16x8 *>(Kh + kl_ * HD + kswz(kl_, ch) * 8) = kh;
+                *reinterpret_cast<f16x8 *>(Kl + kl_ * HD + kswz(kl_, ch) * 8) = kl;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    Vh[(ch * 8 + j) * vld + kl_] = b0[j];
+                    Vh[(ch * 8 + 4 + j) * vld + kl_] = b1[j];
+                    Vl[(ch * 8 + j) * vld + kl_] = (_Float16)((v0[j] - (float)b0[j]) * SC);
+                    Vl[(ch * 8 + 4 + j) * vld + kl_] = (_Float16)((v1[j] - (float)b1[j]) * SC);
+                }
             }
         }
     };
-    const bool single = Tk <= kc;  // one chunk: staged once, shared by every query pass
-    if (single) {
-        stage(0);
-        __syncthreads();
-    }
+    const bool single = Tk <= kc;  // one chunk: staged once (inside the first query pass, behind its Q loads), shared by every pass
     const int q_end = cls_only ? 1 : T;
     const float qscale = 0.125f * 1.44269504088896340736f;
     for (int qp0 = 0; qp0 < q_end; qp0 += 32 * NW) {  // query pass: 32 queries per wave (uniform loop: the barriers below)
@@ -338,9 +351,16 @@ __global__ void __launch_bounds__(64 * NW, 2) attention_split_kernel(const float
         f16x8 qh[4], ql[4];
         {
             const float *qp = qkv + (size_t)(tok0 + min(qb0 + i, T - 1)) * ld + h * HD + 32 * g;
+            f32x4 xq[8];
+#pragma unroll
+            for (int sx = 0; sx < 8; ++sx) xq[sx] = *reinterpret_cast<const f32x4 *>(qp + sx * 4);
+            if (single && qp0 == 0) {  // uniform; the Q loads above are in flight while the panel is fetched
+                stage(0, std::integral_constant<int, 4>{});
+                __syncthreads();
+            }
 #pragma unroll
             for (int sx = 0; sx < 4; ++sx) {
-                f32x4 x0 = *reinterpret_cast<const f32x4 *>(qp + sx * 8), x1 = *reinterpret_cast<const f32x4 *>(qp + sx * 8 + 4);
+                f32x4 x0 = xq[2 * sx], x1 = xq[2 * sx + 1];
                 x0 = x0 * qscale;
                 x1 = x1 * qscale;
                 const f16x4 a0 = cvt_f16x4_pinned(x0), a1 = cvt_f16x4_pinned(x1);
@@ -357,7 +377,7 @@ __global__ void __launch_bounds__(64 * NW, 2) attention_split_kernel(const float
         for (int k0 = 0; k0 < Tk; k0 += kc) {
             if (!single) {
                 __syncthreads();  // the previous chunk (or pass) is no longer read
-                stage(k0);
+                stage(k0, std::integral_constant<int, 1>{});
                 __syncthreads();
             }
             if (!active) continue;
@@ -459,6 +479,8 @@ size_t attention_split_lds_bytes(int max_seq_len) {
 }
 
 // qkv [T, 3 n_heads 64] fp32 -> ctx_pair [T or n_seq, 2 n_heads 64] fp16 pair rows; any sequence length (keys staged 256 at a time).
+// Measured and rejected (round 4): the sequences of <= 64 tokens in a second launch of 2-wave / 33 KB workgroups (4 per CU, no idle
+// waves): 179.6 + 66.3 us against 242.1 us in one launch.
 int launch_attention_split(const float *qkv, _Float16 *ctx_pair, const int4 *desc, int n_seq, int n_heads, int max_seq_len,
                            int cls_only, hipStream_t st) {
     if (n_seq <= 0) return ANCE_OK;
