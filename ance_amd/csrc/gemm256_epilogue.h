@@ -220,31 +220,24 @@ __device__ __forceinline__ void gemm256_epilogue(const GemmArgs &G, f32x16 (&acc
         // out16 = fp16(v) (the next GEMM's token operand AND the high half of the stream), out_lo = fp16(v - out16)
         // (v - fp16(v) is exact in fp32; the pair carries 22 bits).  Per row and 64-column slice the (mean, M2) of v go
         // to part_out[] -- the consumers combine the N / 64 slices of a row (Chan) into (mean, rstd) in their own epilogues.
-        // Every global access is 16 bytes per lane: 8 lanes cover the 128-byte slice of a row, an instruction covers 8 rows.  With
-        // 8-byte accesses (16 lanes per row) a pass was 32 vector-memory instructions per wave and the epilogue was bound by
-        // their ISSUE, not by their bytes.
         float *slab = smem_f + w * 4096;
         constexpr int LS = 68;
-        const int c8 = l & 7;
+        const int c4 = l & 15;
         const float *pb = smem_f + EPB_OFF;
-        f32x4 lng[2], bias_beta[2];
-#pragma unroll
-        for (int hf = 0; hf < 2; ++hf) {
-            lng[hf] = *reinterpret_cast<const f32x4 *>(pb + EPB_VEC + 256 + wn * 64 + c8 * 8 + hf * 4);
-            bias_beta[hf] = *reinterpret_cast<const f32x4 *>(pb + EPB_VEC + wn * 64 + c8 * 8 + hf * 4) +
-                            *reinterpret_cast<const f32x4 *>(pb + EPB_VEC + 512 + wn * 64 + c8 * 8 + hf * 4);
-        }
+        const f32x4 lng = *reinterpret_cast<const f32x4 *>(pb + EPB_VEC + 256 + wn * 64 + c4 * 4);
+        const f32x4 bias_beta = *reinterpret_cast<const f32x4 *>(pb + EPB_VEC + wn * 64 + c4 * 4) +
+                                *reinterpret_cast<const f32x4 *>(pb + EPB_VEC + 512 + wn * 64 + c4 * 4);
         const int n_parts = G.N >> 6, slice = nw0 >> 6;
 #pragma unroll
         for (int y = 0; y < 4; ++y) {
-            f16x8 rh[4], rl[4];
-            float mean[4], rstd[4];
+            f16x4 rh[8], rl[8];
+            float mean[8], rstd[8];
 #pragma unroll
-            for (int it = 0; it < 4; ++it) {
-                const int rr = it * 8 + (l >> 3);
+            for (int it = 0; it < 8; ++it) {
+                const int rr = it * 4 + (l >> 4);
                 const size_t row = (size_t)(mw0 + y * 32 + rr);
-                rh[it] = *reinterpret_cast<const f16x8 *>(G.res_hi + row * G.ldc + nw0 + c8 * 8);
-                rl[it] = *reinterpret_cast<const f16x8 *>(G.res_lo + row * G.ldc + nw0 + c8 * 8);
+                rh[it] = *reinterpret_cast<const f16x4 *>(G.res_hi + row * G.ldc + nw0 + c4 * 4);
+                rl[it] = *reinterpret_cast<const f16x4 *>(G.res_lo + row * G.ldc + nw0 + c4 * 4);
                 mean[it] = pb[EPB_STATS + 2 * (wm * 128 + y * 32 + rr)];
                 rstd[it] = pb[EPB_STATS + 2 * (wm * 128 + y * 32 + rr) + 1];
             }
@@ -258,75 +251,63 @@ __device__ __forceinline__ void gemm256_epilogue(const GemmArgs &G, f32x16 (&acc
                         f32x4{a[4 * rq], a[4 * rq + 1], a[4 * rq + 2], a[4 * rq + 3]};
                 }
             epi_sync<WAVE_SYNC>();
-            // running pointers (a row step is 8 rows): 64-bit address arithmetic per store was a fifth of this loop
-            const size_t row0 = (size_t)(mw0 + y * 32 + (l >> 3));
-            _Float16 *ph = G.out16 + row0 * G.ldc + nw0 + c8 * 8;
-            _Float16 *pl = G.out_lo + row0 * G.ldc + nw0 + c8 * 8;
-            const size_t rstep = (size_t)8 * G.ldc;
-            f32x4 vv[4][2];
+            // running pointers (a row step is 4 rows): 64-bit address arithmetic per store was a fifth of this loop
+            const size_t row0 = (size_t)(mw0 + y * 32 + (l >> 4));
+            _Float16 *ph = G.out16 + row0 * G.ldc + nw0 + c4 * 4;
+            _Float16 *pl = G.out_lo + row0 * G.ldc + nw0 + c4 * 4;
+            const size_t rstep = (size_t)4 * G.ldc;
+            f32x4 vv[8];
 #pragma unroll
-            for (int it = 0; it < 4; ++it) {
-                const int rr = it * 8 + (l >> 3);
-                f16x8 hi8, lo8;
-#pragma unroll
-                for (int hf = 0; hf < 2; ++hf) {
-                    // acc + bias + LayerNorm(hi + lo) = acc + hi a + (lo a + (bias + beta - mean a)),  a = rstd gamma
-                    f32x4 v = *reinterpret_cast<const f32x4 *>(slab + rr * LS + c8 * 8 + hf * 4);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float a = rstd[it] * lng[hf][e];
-                        const float b0 = __builtin_fmaf(-mean[it], a, bias_beta[hf][e]);
-                        v[e] += __builtin_fmaf((float)rh[it][hf * 4 + e], a, __builtin_fmaf((float)rl[it][hf * 4 + e], a, b0));
-                    }
-                    const f16x4 hi = cvt_f16x4_pinned(v);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        hi8[hf * 4 + e] = hi[e];
-                        lo8[hf * 4 + e] = (_Float16)(v[e] - (float)hi[e]);
-                    }
-                    vv[it][hf] = v;
-                }
-                *reinterpret_cast<f16x8 *>(ph + it * rstep) = hi8;
-                *reinterpret_cast<f16x8 *>(pl + it * rstep) = lo8;
-            }
-            // slice statistics of the 4 x 8 rows together: independent 8-lane reductions interleave (a DPP add right behind
-            // the add that feeds it needs wait states).  Lanes 8 j .. 8 j + 7 hold one row: two quad steps, then the half-row
-            // mirror (the quads are uniform by then).
-            float s4[4], q4[4];
-#pragma unroll
-            for (int it = 0; it < 4; ++it)
-                s4[it] = ((vv[it][0][0] + vv[it][0][1]) + (vv[it][0][2] + vv[it][0][3])) +
-                         ((vv[it][1][0] + vv[it][1][1]) + (vv[it][1][2] + vv[it][1][3]));
-#pragma unroll
-            for (int it = 0; it < 4; ++it) s4[it] += __builtin_amdgcn_update_dpp(0.f, s4[it], 0xB1, 0xF, 0xF, true);
-#pragma unroll
-            for (int it = 0; it < 4; ++it) s4[it] += __builtin_amdgcn_update_dpp(0.f, s4[it], 0x4E, 0xF, 0xF, true);
-#pragma unroll
-            for (int it = 0; it < 4; ++it) s4[it] += __builtin_amdgcn_update_dpp(0.f, s4[it], 0x141, 0xF, 0xF, true);
-#pragma unroll
-            for (int it = 0; it < 4; ++it) {
-                const float m64 = s4[it] * (1.0f / 64.0f);
-                s4[it] = m64;
-                float q = 0.f, q1 = 0.f;
+            for (int it = 0; it < 8; ++it) {
+                const int rr = it * 4 + (l >> 4);
+                // acc + bias + LayerNorm(hi + lo) = acc + hi a + (lo a + (bias + beta - mean a)),  a = rstd gamma
+                f32x4 v = *reinterpret_cast<const f32x4 *>(slab + rr * LS + c4 * 4);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float d0 = vv[it][0][e] - m64, d1 = vv[it][1][e] - m64;
-                    q = __builtin_fmaf(d0, d0, q);
-                    q1 = __builtin_fmaf(d1, d1, q1);
+                    const float a = rstd[it] * lng[e];
+                    const float b0 = __builtin_fmaf(-mean[it], a, bias_beta[e]);
+                    v[e] += __builtin_fmaf((float)rh[it][e], a, __builtin_fmaf((float)rl[it][e], a, b0));
                 }
-                q4[it] = q + q1;
+                const f16x4 hi = cvt_f16x4_pinned(v);
+                const f16x4 lo = f16x4{(_Float16)(v[0] - (float)hi[0]), (_Float16)(v[1] - (float)hi[1]),
+                                       (_Float16)(v[2] - (float)hi[2]), (_Float16)(v[3] - (float)hi[3])};
+                *reinterpret_cast<f16x4 *>(ph + it * rstep) = hi;
+                *reinterpret_cast<f16x4 *>(pl + it * rstep) = lo;
+                vv[it] = v;
+            }
+            // slice statistics of the 8 rows together: eight independent 16-lane reductions interleave (a DPP add right
+            // behind the add that feeds it needs wait states; one row at a time the chain was serial)
+            float s8[8], q8[8];
+#pragma unroll
+            for (int it = 0; it < 8; ++it) s8[it] = (vv[it][0] + vv[it][1]) + (vv[it][2] + vv[it][3]);
+#pragma unroll
+            for (int it = 0; it < 8; ++it) s8[it] += __builtin_amdgcn_update_dpp(0.f, s8[it], 0xB1, 0xF, 0xF, true);
+#pragma unroll
+            for (int it = 0; it < 8; ++it) s8[it] += __builtin_amdgcn_update_dpp(0.f, s8[it], 0x4E, 0xF, 0xF, true);
+#pragma unroll
+            for (int it = 0; it < 8; ++it) s8[it] += __builtin_amdgcn_update_dpp(0.f, s8[it], 0x124, 0xF, 0xF, true);
+#pragma unroll
+            for (int it = 0; it < 8; ++it) s8[it] += __builtin_amdgcn_update_dpp(0.f, s8[it], 0x128, 0xF, 0xF, true);
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const float m64 = s8[it] * (1.0f / 64.0f);
+                s8[it] = m64;
+                const float d0 = vv[it][0] - m64, d1 = vv[it][1] - m64, d2 = vv[it][2] - m64, d3 = vv[it][3] - m64;
+                q8[it] = (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
             }
 #pragma unroll
-            for (int it = 0; it < 4; ++it) q4[it] += __builtin_amdgcn_update_dpp(0.f, q4[it], 0xB1, 0xF, 0xF, true);
+            for (int it = 0; it < 8; ++it) q8[it] += __builtin_amdgcn_update_dpp(0.f, q8[it], 0xB1, 0xF, 0xF, true);
 #pragma unroll
-            for (int it = 0; it < 4; ++it) q4[it] += __builtin_amdgcn_update_dpp(0.f, q4[it], 0x4E, 0xF, 0xF, true);
+            for (int it = 0; it < 8; ++it) q8[it] += __builtin_amdgcn_update_dpp(0.f, q8[it], 0x4E, 0xF, 0xF, true);
 #pragma unroll
-            for (int it = 0; it < 4; ++it) q4[it] += __builtin_amdgcn_update_dpp(0.f, q4[it], 0x141, 0xF, 0xF, true);
-            if (c8 == 0) {
+            for (int it = 0; it < 8; ++it) q8[it] += __builtin_amdgcn_update_dpp(0.f, q8[it], 0x124, 0xF, 0xF, true);
+#pragma unroll
+            for (int it = 0; it < 8; ++it) q8[it] += __builtin_amdgcn_update_dpp(0.f, q8[it], 0x128, 0xF, 0xF, true);
+            if (c4 == 0) {
                 float *pp = G.part_out + (row0 * n_parts + slice) * 2;
-                const size_t pstep = (size_t)8 * n_parts * 2;
+                const size_t pstep = (size_t)4 * n_parts * 2;
 #pragma unroll
-                for (int it = 0; it < 4; ++it) *reinterpret_cast<float2 *>(pp + it * pstep) = make_float2(s4[it], q4[it]);
+                for (int it = 0; it < 8; ++it) *reinterpret_cast<float2 *>(pp + it * pstep) = make_float2(s8[it], q8[it]);
             }
 #ifdef ANCE_MEASURE
             if (pass_stamps && w == 0 && l == 0) pass_stamps[y] = __builtin_amdgcn_s_memrealtime();
