@@ -101,6 +101,12 @@ __device__ __forceinline__ bool epb_stats(const GemmArgs &G, float *smem_f, int 
     return __builtin_amdgcn_readfirstlane(__syncthreads_or(wide)) != 0;  // (readfirstlane: the compiler must know it is uniform)
 }
 
+#ifdef ANCE_MEASURE
+// measurement library only (WRONG results): bit 0 -- the RESLN epilogue reads its residual rows from rows 0..31 of the tile's
+// slice (cache-resident), bit 1 -- it writes its output rows there: how much of the epilogue is its HBM traffic
+__device__ int g_res_ablate = 0;
+#endif
+
 template <int EPI_, bool WAVE_SYNC = false>
 __device__ __forceinline__ void gemm256_epilogue(const GemmArgs &G, f32x16 (&acc)[2][4], float *smem_f, int m0, int n0,
                                                  int w, int l, unsigned long long *pass_stamps = nullptr) {
@@ -235,7 +241,11 @@ __device__ __forceinline__ void gemm256_epilogue(const GemmArgs &G, f32x16 (&acc
 #pragma unroll
             for (int it = 0; it < 8; ++it) {
                 const int rr = it * 4 + (l >> 4);
+#ifdef ANCE_MEASURE
+                const size_t row = (g_res_ablate & 1) ? (size_t)rr : (size_t)(mw0 + y * 32 + rr);
+#else
                 const size_t row = (size_t)(mw0 + y * 32 + rr);
+#endif
                 rh[it] = *reinterpret_cast<const f16x4 *>(G.res_hi + row * G.ldc + nw0 + c4 * 4);
                 rl[it] = *reinterpret_cast<const f16x4 *>(G.res_lo + row * G.ldc + nw0 + c4 * 4);
                 mean[it] = pb[EPB_STATS + 2 * (wm * 128 + y * 32 + rr)];
@@ -253,8 +263,13 @@ __device__ __forceinline__ void gemm256_epilogue(const GemmArgs &G, f32x16 (&acc
             epi_sync<WAVE_SYNC>();
             // running pointers (a row step is 4 rows): 64-bit address arithmetic per store was a fifth of this loop
             const size_t row0 = (size_t)(mw0 + y * 32 + (l >> 4));
-            _Float16 *ph = G.out16 + row0 * G.ldc + nw0 + c4 * 4;
-            _Float16 *pl = G.out_lo + row0 * G.ldc + nw0 + c4 * 4;
+#ifdef ANCE_MEASURE
+            const size_t orow0 = (g_res_ablate & 2) ? (size_t)(l >> 4) : row0;
+#else
+            const size_t orow0 = row0;
+#endif
+            _Float16 *ph = G.out16 + orow0 * G.ldc + nw0 + c4 * 4;
+            _Float16 *pl = G.out_lo + orow0 * G.ldc + nw0 + c4 * 4;
             const size_t rstep = (size_t)4 * G.ldc;
             f32x4 vv[8];
 #pragma unroll

@@ -453,6 +453,10 @@ extern "C" void ance_debug_gemm_stamps(void *d_stamps) {
     unsigned long long *p = ance::g_gemm_stamps_host;
     (void)hipMemcpyToSymbol(HIP_SYMBOL(ance::g_gemm_stamps), &p, sizeof(p));
 }
+// measurement library only (WRONG results): see g_res_ablate in gemm256_epilogue.h
+extern "C" void ance_debug_gemm_res_ablate(int bits) {
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(ance::g_res_ablate), &bits, sizeof(bits));
+}
 #endif
 
 // Test / measurement hook (include/ance_amd.h): the encoder's GEMM kernel on caller-provided data.
