@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("ANCE_AMD_LIB") or os.path.join(_HERE, "libance_amd.so
 CSRC = os.path.join(_HERE, "csrc")
 
 ANCE_OK = 0
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 c_i32p = ctypes.POINTER(ctypes.c_int32)
 c_i64p = ctypes.POINTER(ctypes.c_int64)
@@ -84,7 +84,9 @@ SYMBOLS = {
                                         ctypes.c_void_p]),
     "ance_debug_gemm_split": (ctypes.c_int, [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                              ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_float,
-                                             ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+                                             ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "ance_pair_layout": (None, [ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int),
+                                ctypes.POINTER(ctypes.c_float)]),
 }
 
 _lib = None

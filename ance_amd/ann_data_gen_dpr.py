@@ -189,7 +189,8 @@ def get_arguments(argv=None):
     p.add_argument("--trivia_test_qa_path", default=None, type=str, required=True)
     p.add_argument("--max_tokens", default=65536, type=int)
     p.add_argument("--seed", default=None, type=int)
-    p.add_argument("--encoder_precision", default=None, choices=["fp16", "split", "fp32"])
+    p.add_argument("--encoder_precision", default="split", choices=["fp16", "split", "fp32"],
+                   help="see ance_amd.ann_data_gen: split (default) is fp32-grade like the reference's forward, fp16 the fast mode")
     p.add_argument("--host_workers", default=None, type=int, help="has_answer worker processes on rank 0 (default: up to 32)")
     return p.parse_args(argv)
 

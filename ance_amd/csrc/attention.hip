@@ -264,9 +264,10 @@ __global__ void __launch_bounds__(64 * NW, 3) attention_kernel(const AttnArgs A)
 
 // ---- split (fp32-grade) attention: fp16 (hi, lo') pairs on the matrix cores, fp32 softmax ---------------------------------------
 // The split encoder mode (encoder.hip) keeps Q | K | V in fp32 (qkv: [T, 2304] rows, as the fp32 path of precise32.h) and wants
-// the context rows back as pair rows [hi (768) | lo' (768)].  Same structure as attention_kernel -- one workgroup per (sequence,
+// the context rows back as pair rows (common.h: pair_store4).  Same structure as attention_kernel -- one workgroup per (sequence,
 // head), K and V^T of the head staged once in LDS, S^T = K Q^T, online softmax per lane, O^T = V^T P^T -- but every operand is
-// split while it is staged (v = hi + lo' 2^-11, as in the split GEMM) and every product is three MFMAs:
+// split while it is staged (v = hi + lo' 2^-11 -- internal to this kernel, two accumulator sets; the split GEMM's pair rows carry
+// unscaled lo halves, see common.h) and every product is three MFMAs:
 //     S^T = 2^-11 (K_hi Q_lo'^T + K_lo' Q_hi^T) + K_hi Q_hi^T          (Q carries log2(e) / 8: the softmax runs on exp2)
 //     O^T = 2^-11 (V_hi P_lo'^T + V_lo' P_hi^T) + V_hi P_hi^T          (two accumulator sets, combined once at the end)
 // LDS: 4 x keys x 64 halves + pads = 66 KB at 128 keys, 132 KB at 256; longer sequences stage their keys 256 at a time (the
@@ -450,7 +451,7 @@ __global__ void __launch_bounds__(64 * NW, 2) attention_split_kernel(const float
         const float inv = 1.0f / l_tot;
         if (qb0 + i < q_end) {
             const size_t orow = cls_only ? (size_t)s : (size_t)(tok0 + qb0 + i);
-            _Float16 *op = ctx_pair + orow * (size_t)(2 * n_heads * HD) + h * HD + 4 * g;
+            _Float16 *orp = ctx_pair + orow * (size_t)(2 * n_heads * HD);  // pair row (common.h) of n_heads * 64 columns
 #pragma unroll
             for (int db = 0; db < 2; ++db) {
                 const f32x16 &om = db == 0 ? om0 : om1;
@@ -460,11 +461,7 @@ __global__ void __launch_bounds__(64 * NW, 2) attention_split_kernel(const float
                     f32x4 v;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) v[j] = __builtin_fmaf(oc[4 * rq + j], SI, om[4 * rq + j]) * inv;
-                    const f16x4 hi = cvt_f16x4_pinned(v);
-                    const f16x4 lo = f16x4{(_Float16)((v[0] - (float)hi[0]) * SC), (_Float16)((v[1] - (float)hi[1]) * SC),
-                                           (_Float16)((v[2] - (float)hi[2]) * SC), (_Float16)((v[3] - (float)hi[3]) * SC)};
-                    *reinterpret_cast<f16x4 *>(op + db * 32 + 8 * rq) = hi;
-                    *reinterpret_cast<f16x4 *>(op + n_heads * HD + db * 32 + 8 * rq) = lo;
+                    pair_store4(v, orp, n_heads * HD, h * HD + db * 32 + 8 * rq + 4 * g);
                 }
             }
         }

@@ -65,6 +65,47 @@ __device__ __forceinline__ f16x4 cvt_f16x4_pinned(const f32x4 v) {
     return h;
 }
 
+// ---- fp16 (hi, lo) pair rows of the split (fp32-grade) encoder mode ---------------------------------------------------------
+// A W-wide fp32 row v travels as 2 W halves, v = hi + lo PAIR_LO_INV with hi = fp16(v), lo = fp16((v - hi) PAIR_LO_SCALE)
+// (v - hi is exact in fp32).  Round 5 layout ("blocked"): 32-column blocks [hi (32) | lo (32)], lo UNSCALED -- a 64-half LDS row
+// of the GEMM's K-tile then holds a 32-deep k-slice of BOTH halves of an operand row, 128 contiguous bytes in memory, and the
+// three products hi x hi, lo x hi, hi x lo of a k-step accumulate into ONE fp32 accumulator (same scale): each operand tile is
+// staged once and read from LDS once for three MFMAs (gemm256_f16.hip: gemm256_split_kernel).  Unscaled lo halves of small
+// elements are fp16 subnormals (kept by the conversion and by the MFMA: tests/test_gpu_gemm.py::test_mfma_keeps_f16_subnormals);
+// below 2^-24 they lose at most 2^-25 ABSOLUTE, which is why weights are stored times a per-matrix power of two that puts
+// their largest element in [2^13, 2^14) (encoder.hip: split_weight_kernel; undone in the GEMM epilogue).
+// ANCE_SPLIT_V1 (measurement builds only, `make splitv1`): round 4's format -- rows [hi (W) | lo' (W)], lo' = (v - hi) 2^11, three
+// K segments with a rescale in between -- for same-box A/B runs.
+#ifdef ANCE_SPLIT_V1
+constexpr float PAIR_LO_SCALE = 2048.0f, PAIR_LO_INV = 1.0f / 2048.0f;
+__host__ __device__ __forceinline__ int pair_hi_col(int n, int W) { (void)W; return n; }
+__host__ __device__ __forceinline__ int pair_lo_col(int n, int W) { return n + W; }
+#else
+constexpr float PAIR_LO_SCALE = 1.0f, PAIR_LO_INV = 1.0f;
+__host__ __device__ __forceinline__ int pair_hi_col(int n, int W) { (void)W; return ((n >> 5) << 6) + (n & 31); }
+__host__ __device__ __forceinline__ int pair_lo_col(int n, int W) { (void)W; return ((n >> 5) << 6) + (n & 31) + 32; }
+#endif
+// v (4 consecutive columns) -> the two f16x4 of its pair; the hi that is stored is the hi the residual was formed from
+__device__ __forceinline__ void pair_split4(const f32x4 v, f16x4 *hi, f16x4 *lo) {
+#pragma clang fp contract(off)
+    const f16x4 h = cvt_f16x4_pinned(v);
+    *hi = h;
+    *lo = f16x4{(_Float16)((v[0] - (float)h[0]) * PAIR_LO_SCALE), (_Float16)((v[1] - (float)h[1]) * PAIR_LO_SCALE),
+                (_Float16)((v[2] - (float)h[2]) * PAIR_LO_SCALE), (_Float16)((v[3] - (float)h[3]) * PAIR_LO_SCALE)};
+}
+// store / load columns n .. n + 3 (n a multiple of 4) of a pair row of width W
+__device__ __forceinline__ void pair_store4(const f32x4 v, _Float16 *row, int W, int n) {
+    f16x4 h, r;
+    pair_split4(v, &h, &r);
+    *reinterpret_cast<f16x4 *>(row + pair_hi_col(n, W)) = h;
+    *reinterpret_cast<f16x4 *>(row + pair_lo_col(n, W)) = r;
+}
+__device__ __forceinline__ f32x4 pair_load4(const _Float16 *row, int W, int n) {
+    const f16x4 h = *reinterpret_cast<const f16x4 *>(row + pair_hi_col(n, W)), r = *reinterpret_cast<const f16x4 *>(row + pair_lo_col(n, W));
+    return f32x4{(float)h[0] + (float)r[0] * PAIR_LO_INV, (float)h[1] + (float)r[1] * PAIR_LO_INV, (float)h[2] + (float)r[2] * PAIR_LO_INV,
+                 (float)h[3] + (float)r[3] * PAIR_LO_INV};
+}
+
 __device__ inline int lane_id() { return (int)(threadIdx.x & 63); }
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }

@@ -402,25 +402,17 @@ __device__ __forceinline__ float gelu_exact(float x) {
     return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
 }
 
-// v -> (hi, lo'): hi = fp16(v), lo' = fp16((v - hi) 2^11).  v - hi is exact in fp32; the scale keeps lo' in the fp16 normal range
-constexpr float SPLIT_SCALE = 2048.0f, SPLIT_INV = 1.0f / 2048.0f;
-__device__ __forceinline__ void split4(const f32x4 v, f16x4 *hi, f16x4 *lo) {
-#pragma clang fp contract(off)
-    const f16x4 h = cvt_f16x4_pinned(v);
-    *hi = h;
-    *lo = f16x4{(_Float16)((v[0] - (float)h[0]) * SPLIT_SCALE), (_Float16)((v[1] - (float)h[1]) * SPLIT_SCALE),
-                (_Float16)((v[2] - (float)h[2]) * SPLIT_SCALE), (_Float16)((v[3] - (float)h[3]) * SPLIT_SCALE)};
-}
-
 // One structure for the three of them: 4 passes over the wave's 128 rows, each through the wave-private fp32 slab
 // [32 m][64 n] (as EPI_RES32 / EPI_RESLN), so that on read-back a lane owns 4 consecutive columns of a row and global
 // traffic is whole 16-byte (fp32) or 8-byte (fp16) row segments.
-//   EPI_S_QKV    out32[m][n]         = r (acc - mu c) + b'                   folded LayerNorm, fp32 out (Q | K | V)
-//   EPI_S_GELU   out16 pair [m][n]   = split(gelu_exact(r (acc - mu c) + b'))   row = [hi (N) | lo' (N)], ldc = 2 N
-//   EPI_S_RESLN  out16 pair [m][n]   = split(acc + bias + LayerNorm(res_hi + res_lo' 2^-11)), + slice statistics (part_out)
+//   EPI_S_QKV    out32[m][n]         = r (acc' - mu c) + b'                   folded LayerNorm, fp32 out (Q | K | V)
+//   EPI_S_GELU   out16 pair [m][n]   = pair(gelu_exact(r (acc' - mu c) + b'))   pair row of 2 N halves (common.h), ldc = 2 N
+//   EPI_S_RESLN  out16 pair [m][n]   = pair(acc' + bias + LayerNorm(residual pair)), + slice statistics (part_out)
+// acc' = acc winv: winv is the inverse of the power of two the weight was stored with (exact; it rides on the row's rstd or in
+// the one fma that adds the residual, so it costs no instruction).
 template <int EPI>
 __device__ __forceinline__ void gemm256_epilogue_split(const GemmArgs &G, f32x16 (&acc)[2][4], float *smem_f, int m0, int n0,
-                                                       int w, int l) {
+                                                       int w, int l, float winv) {
 #pragma clang fp contract(off)
     const int g = l >> 5, i = l & 31;
     const int wm = w >> 2, wn = w & 3;
@@ -442,9 +434,9 @@ __device__ __forceinline__ void gemm256_epilogue_split(const GemmArgs &G, f32x16
         for (int it = 0; it < 8; ++it) {
             const int rr = it * 4 + (l >> 4);
             if constexpr (EPI == EPI_S_RESLN) {
-                const _Float16 *rp = G.res_hi + (size_t)(mw0 + y * 32 + rr) * G.ldr + nw0 + c4 * 4;
-                rh[it] = *reinterpret_cast<const f16x4 *>(rp);
-                rl[it] = *reinterpret_cast<const f16x4 *>(rp + G.N);
+                const _Float16 *rp = G.res_hi + (size_t)(mw0 + y * 32 + rr) * G.ldr;
+                rh[it] = *reinterpret_cast<const f16x4 *>(rp + pair_hi_col(nw0 + c4 * 4, G.N));
+                rl[it] = *reinterpret_cast<const f16x4 *>(rp + pair_lo_col(nw0 + c4 * 4, G.N));
             }
             mean[it] = pb[EPB_STATS + 2 * (wm * 128 + y * 32 + rr)];
             rstd[it] = pb[EPB_STATS + 2 * (wm * 128 + y * 32 + rr) + 1];
@@ -470,29 +462,21 @@ __device__ __forceinline__ void gemm256_epilogue_split(const GemmArgs &G, f32x16
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float a = rstd[it] * v1[e];
-                    const float res = (float)rh[it][e] + (float)rl[it][e] * SPLIT_INV;  // exact in fp32: 22 bits
-                    v[e] += __builtin_fmaf(res - mean[it], a, v0[e] + v2[e]);
+                    const float res = (float)rh[it][e] + (float)rl[it][e] * PAIR_LO_INV;  // exact in fp32: 22 bits
+                    v[e] = __builtin_fmaf(v[e], winv, __builtin_fmaf(res - mean[it], a, v0[e] + v2[e]));
                 }
-                f16x4 hi, lo;
-                split4(v, &hi, &lo);
-                _Float16 *op = G.out16 + row * G.ldc + nw0 + c4 * 4;
-                *reinterpret_cast<f16x4 *>(op) = hi;
-                *reinterpret_cast<f16x4 *>(op + G.N) = lo;
+                pair_store4(v, G.out16 + row * G.ldc, G.N, nw0 + c4 * 4);
                 vv[it] = v;
             } else {
-                const float mr = mean[it] * rstd[it];
+                const float mr = mean[it] * rstd[it], rw = rstd[it] * winv;  // r (acc winv) = acc (r winv): winv is a power of two
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(v[e], rstd[it], __builtin_fmaf(-mr, v1[e], v0[e]));
+                for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(v[e], rw, __builtin_fmaf(-mr, v1[e], v0[e]));
                 if constexpr (EPI == EPI_S_QKV) {
                     *reinterpret_cast<f32x4 *>(G.out32 + row * G.ldc + nw0 + c4 * 4) = v;
                 } else {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = gelu_exact(v[e]);
-                    f16x4 hi, lo;
-                    split4(v, &hi, &lo);
-                    _Float16 *op = G.out16 + row * G.ldc + nw0 + c4 * 4;
-                    *reinterpret_cast<f16x4 *>(op) = hi;
-                    *reinterpret_cast<f16x4 *>(op + G.N) = lo;
+                    pair_store4(v, G.out16 + row * G.ldc, G.N, nw0 + c4 * 4);
                 }
             }
         }

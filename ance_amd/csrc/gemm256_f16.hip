@@ -210,20 +210,33 @@ __global__ void __launch_bounds__(G256_THREADS, 2) gemm256_f16_desc_kernel(const
     if constexpr (EPB) epb_issue<EPI>(G, smem_f, m0, n0, w, l);
     constexpr bool FOLDK = EPI == EPI_QK_F || EPI == EPI_GELU_F || EPI == EPI_VT_F;
     if constexpr (FOLDK) {
-        // ONE copy of the main loop, entered a second time only by a tile with a token whose |mean| >> std: that pass adds
-        // lo . W^T (the K loop over the lo halves of the token operand; the identity  r (acc - mu c) + b'  holds for any
-        // operand, so nothing else changes).  Uniform branch, taken by no tile of a random-init model.
-#pragma nounroll
-        for (int pass = 0;; ++pass) {
-            P.run(G.K / TK, acc);
-            if (pass) break;
-            GSTAMP(1);
-            const bool wide = epb_stats(G, smem_f, tid);
-            if (!(wide && G.tok_lo)) break;
-            if constexpr (EPI == EPI_VT_F)
-                P.S.rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16 *>(G.tok_lo + (size_t)n0 * G.ldb), 0, (int)(256u * (uint32_t)G.ldb * 2u), 0x00020000);
-            else
-                P.S.ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16 *>(G.tok_lo + (size_t)m0 * G.lda), 0, (int)(256u * (uint32_t)G.lda * 2u), 0x00020000);
+        // A tile with a token whose |mean| >> std runs the K loop a second time over the lo halves of the token operand:
+        // acc += lo . W^T (the identity  r (acc - mu c) + b'  holds for any operand, so nothing else changes).  Uniform branch,
+        // taken by no tile of a random-init model.  The second pass is MASKED per row: only the wide-mean tokens feed their lo
+        // halves, every other lane feeds zeros -- the bits of a row therefore depend on that row alone, not on which tokens
+        // share its tile (micro-batch composition, shard boundaries, stale pad rows): ADVICE r4, tests/test_gpu_encoder.py::
+        // test_fp16_rows_do_not_depend_on_their_tile_mates.
+        P.run(G.K / TK, acc);
+        GSTAMP(1);
+        const bool wide = epb_stats(G, smem_f, tid);
+        if (wide && G.tok_lo) {
+            Pipe256T<PipeSrcDesc, false, true, true, false, true> P2;
+            P2.init(smem, w, l);
+            P2.S = P.S;
+            const float *st = smem_f + EPB_OFF + EPB_STATS;
+            const int i = l & 31;
+            auto tok_wide = [&](int t) { return __builtin_fabsf(st[2 * t]) * st[2 * t + 1] > FOLD_WIDE_MEAN; };
+            if constexpr (EPI == EPI_VT_F) {  // tokens are the B-operand rows n = wn * 64 + x * 32 + i
+                P2.S.rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16 *>(G.tok_lo + (size_t)n0 * G.ldb), 0, (int)(256u * (uint32_t)G.ldb * 2u), 0x00020000);
+                P2.keep_b = (tok_wide((w & 3) * 64 + i) ? 1u : 0u) | (tok_wide((w & 3) * 64 + 32 + i) ? 2u : 0u);
+            } else {                          // tokens are the A-operand rows m = wm * 128 + y * 32 + i
+                P2.S.ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16 *>(G.tok_lo + (size_t)m0 * G.lda), 0, (int)(256u * (uint32_t)G.lda * 2u), 0x00020000);
+                unsigned k = 0;
+#pragma unroll
+                for (int y = 0; y < 4; ++y) k |= tok_wide((w >> 2) * 128 + y * 32 + i) ? (1u << y) : 0u;
+                P2.keep_a = k;
+            }
+            P2.run(G.K / TK, acc);
         }
     } else {
         P.run(G.K / TK, acc);
@@ -240,13 +253,19 @@ __global__ void __launch_bounds__(G256_THREADS, 2) gemm256_f16_desc_kernel(const
     GSTAMP(3);
 }
 
-// SPLIT (fp32-grade) GEMM: C = A B^T with both operands as fp16 (hi, lo') pairs (rows [hi (K) | lo' (K)], v = hi + lo' 2^-11),
-//   C = 2^-11 (A_lo' B_hi^T + A_hi B_lo'^T) + A_hi B_hi^T
-// on the same 256 x 256 x 64 ping-pong pipeline: 3 K / 64 K-tiles in one stream (PipeSrcSplit moves the SGPR offset of the
-// LDS-DMA from segment to segment), one multiplication of the 128 accumulator registers by 2^-11 after the two correction
-// segments.  Every partial product is exact in fp32 (11 x 11 bits), the dropped lo' x lo' term is 2^-22 relative: an
-// fp32-grade result at a third of the fp16 MFMA rate (the fp32-input matrix cores run at a sixteenth).  tests/test_split_model.py
-// restates the rounding points on the CPU (3.3e-6 against the fp64 oracle at 12 layers; plain fp32: 2.8e-6).
+// SPLIT (fp32-grade) GEMM: C = A B^T with both operands as fp16 (hi, lo) pair rows (common.h; v = hi + lo),
+//   C = sum_k  A_hi B_hi + A_lo B_hi + A_hi B_lo                  (the dropped lo x lo term is 2^-22 relative)
+// Round 5: the pair rows are BLOCKED -- 32 columns of hi, then the same 32 columns of lo -- so the operand matrices look like
+// plain [rows, 2 K] fp16 matrices to the staging side (PipeSrcDesc, 128 contiguous bytes per row and K-tile, exactly the fp16
+// GEMM's access pattern) and a K-tile in LDS holds a 32-deep k-slice of hi AND lo of both operands: FOUR operand tiles staged
+// and read once for THREE products (Pipe256T<.., PAIR3>: 48 MFMAs per K-tile and wave instead of 32), all into one accumulator
+// set.  Round 4 ran three passes over [hi | lo'] rows (six staged tiles per three products, a 2^-11 rescale between the
+// passes): per MFMA this loop issues two thirds of the LDS-DMAs, ds_reads and barriers -- the resources the K loop is bound by
+// (DESIGN.md 3.2).  One accumulator means one scale: lo is NOT multiplied by 2^11 any more; activations are O(1) (their
+// elements below 2^-3 have subnormal lo halves: at most 2^-25 absolute), weights are stored times a per-matrix power of two
+// (G.wscale_inv undoes it in the epilogue).  Every partial product is exact in fp32 (11 x 11 bits); fp32 accumulation is what
+// is left.  tests/test_split_model.py restates the rounding points on the CPU (3.0e-6 against the fp64 oracle at 12 layers;
+// plain fp32: 2.8e-6).
 template <int EPI>
 __global__ void __launch_bounds__(G256_THREADS, 2) gemm256_split_kernel(const GemmArgs G) {
     extern __shared__ __attribute__((aligned(16))) float smem_f[];
@@ -262,13 +281,15 @@ __global__ void __launch_bounds__(G256_THREADS, 2) gemm256_split_kernel(const Ge
     for (int x = 0; x < 2; ++x)
 #pragma unroll
         for (int y = 0; y < 4; ++y) acc[x][y] = f32x16{0};
+#ifdef ANCE_SPLIT_V1
+    // round 4 (A/B builds): rows [hi (K) | lo' (K)], three K segments lo' x hi, hi x lo', hi x hi, one 2^-11 rescale in between
     Pipe256T<PipeSrcSplit, false, true, true> P;
+#else
+    Pipe256T<PipeSrcDesc, false, true, true, true> P;
+#endif
     P.init(smem, w, l);
     P.S.ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16 *>(G.A + (size_t)m0 * G.lda), 0, (int)(256u * (uint32_t)G.lda * 2u), 0x00020000);
     P.S.rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16 *>(G.B + (size_t)n0 * G.ldb), 0, (int)(256u * (uint32_t)G.ldb * 2u), 0x00020000);
-    const int NK = G.K / TK;
-    P.S.nk = NK;
-    P.S.kbytes = G.K * 2;
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -277,18 +298,26 @@ __global__ void __launch_bounds__(G256_THREADS, 2) gemm256_split_kernel(const Ge
             P.S.voff[h][j] = (uint32_t)(pipe_a_tile_row(h, r) * G.lda + ch) * 2u;
             P.S.voff[2 + h][j] = (uint32_t)(pipe_b_tile_row(h, r) * G.ldb + ch) * 2u;
         }
+    const float winv = G.wscale_inv ? *G.wscale_inv : 1.0f;  // wave-uniform: a scalar load, long back when the epilogue starts
     epb_issue<EPI>(G, smem_f, m0, n0, w, l);
+#ifdef ANCE_SPLIT_V1
+    const int NK = G.K / TK;
+    P.S.nk = NK;
+    P.S.kbytes = G.K * 2;
     P.prologue();
     P.enter();
     P.tiles_streaming(2 * NK, acc);   // the two correction segments (both carry the factor 2^11)
 #pragma unroll
     for (int x = 0; x < 2; ++x)
 #pragma unroll
-        for (int y = 0; y < 4; ++y) acc[x][y] *= SPLIT_INV;
+        for (int y = 0; y < 4; ++y) acc[x][y] *= PAIR_LO_INV;
     P.tiles_final(3 * NK, acc, 2 * NK);  // hi x hi
     P.leave();
+#else
+    P.run(G.K / 32, acc);  // K-tile = 64 halves of a blocked pair row = 32 k of hi and lo
+#endif
     (void)epb_stats(G, smem_f, tid);
-    gemm256_epilogue_split<EPI>(G, acc, smem_f, m0, n0, w, l);
+    gemm256_epilogue_split<EPI>(G, acc, smem_f, m0, n0, w, l, winv);
 }
 
 template <int EPI, bool ABLATE>
@@ -486,20 +515,22 @@ extern "C" int ance_debug_gemm(int ablate, int epi, const void *d_a_f16, const v
     return rc ? rc : check_launch("ance_debug_gemm");
 }
 
-// Test hook (include/ance_amd.h): the SPLIT GEMM with each of its three epilogues on caller-provided pair operands.
+// Test hook (include/ance_amd.h): the SPLIT GEMM with each of its three epilogues on caller-provided pair operands (blocked pair
+// rows: ance_pair_layout); d_wscale_inv: optional device scalar the accumulators are multiplied by (the inverse of the power of
+// two the B operand was stored with).
 extern "C" int ance_debug_gemm_split(int epi, const void *d_a_pair, const void *d_b_pair, int M, int N, int K, const float *d_bias,
                                      const float *d_vec1, const float *d_vec2, const float *d_part, float ln_eps,
-                                     const void *d_res_pair, void *d_out, float *d_part_out, void *stream) {
+                                     const void *d_res_pair, void *d_out, float *d_part_out, const float *d_wscale_inv, void *stream) {
     using namespace ance;
     if (!d_a_pair || !d_b_pair || !d_bias || !d_vec1 || !d_part || !d_out || epi < EPI_S_QKV || epi > EPI_S_RESLN ||
-        (epi == EPI_S_RESLN && (!d_vec2 || !d_res_pair || !d_part_out || N != 768))) {
+        (epi == EPI_S_RESLN && (!d_vec2 || !d_res_pair || !d_part_out || N != 768)) || K % 64 != 0) {
         set_last_error("ance_debug_gemm_split: invalid argument");
         return ANCE_E_INVALID;
     }
     GemmArgs G;
     memset(&G, 0, sizeof(G));
     G.A = (const _Float16 *)d_a_pair; G.lda = 2 * K; G.B = (const _Float16 *)d_b_pair; G.ldb = 2 * K;
-    G.M = M; G.N = N; G.K = K; G.bias = d_bias; G.part_in = d_part; G.ln_eps = ln_eps;
+    G.M = M; G.N = N; G.K = K; G.bias = d_bias; G.part_in = d_part; G.ln_eps = ln_eps; G.wscale_inv = d_wscale_inv;
     if (epi == EPI_S_QKV) {
         G.csum = d_vec1; G.out32 = (float *)d_out; G.ldc = N;
     } else if (epi == EPI_S_GELU) {
@@ -510,4 +541,12 @@ extern "C" int ance_debug_gemm_split(int epi, const void *d_a_pair, const void *
     }
     int rc = launch_gemm_f16(epi, G, (hipStream_t)stream);
     return rc ? rc : check_launch("ance_debug_gemm_split");
+}
+
+// Layout of the split mode's pair rows for tests and tools: column n of a W-wide row -> positions of its hi and lo halves in the
+// 2 W-half row, and the factor lo was multiplied by (1: unscaled; the round-4 A/B build reports 2048 and rows [hi (W) | lo' (W)]).
+extern "C" void ance_pair_layout(int n, int W, int *hi_col, int *lo_col, float *lo_scale) {
+    if (hi_col) *hi_col = ance::pair_hi_col(n, W);
+    if (lo_col) *lo_col = ance::pair_lo_col(n, W);
+    if (lo_scale) *lo_scale = ance::PAIR_LO_SCALE;
 }

@@ -11,8 +11,8 @@ namespace ance {
 // The statistics a tile needs come from part_in: the slice partials of its 256 token rows are copied into LDS by LDS-DMA
 // before the main loop (with the tile's bias / csum / gamma / beta vectors) and combined there when the epilogue starts --
 // no LayerNorm kernel, no statistics kernel, no parameter load left on the epilogue's critical path.
-// EPI_S_*: the SPLIT (fp32-grade) GEMM of gemm256_f16.hip -- operands are fp16 (hi, lo') pairs, three MFMA passes (pipe256.h:
-// PipeSrcSplit); epilogues in gemm256_epilogue.h.
+// EPI_S_*: the SPLIT (fp32-grade) GEMM of gemm256_f16.hip -- operands are fp16 (hi, lo) pair rows, three MFMAs per k-step from four
+// staged operand tiles (pipe256.h: PAIR3); epilogues in gemm256_epilogue.h.
 enum { EPI_QK = 0, EPI_GELU = 1, EPI_RES32 = 2, EPI_VT = 3, EPI_RESLN = 4, EPI_QK_F = 5, EPI_GELU_F = 6, EPI_VT_F = 7,
        EPI_S_QKV = 8, EPI_S_GELU = 9, EPI_S_RESLN = 10, EPI_COUNT = 11 };
 
@@ -48,9 +48,11 @@ struct GemmArgs {
     // folded epilogues, optional: the lo halves of the token operand (same layout as the operand itself).  A tile with a token
     // whose |mean| rstd exceeds FOLD_WIDE_MEAN runs a second K loop over them, so that the operand carries 22 bits there.
     const _Float16 *tok_lo;
-    // split GEMM: operand rows are [hi (K) | lo' (K)] (lda / ldb = 2 K or more); EPI_S_RESLN reads the residual pair rows
-    // [hi (N) | lo' (N)] at row stride ldr and writes pair rows at row stride ldc
+    // split GEMM: operand rows are pair rows (common.h) of 2 K halves (lda / ldb = 2 K or more); EPI_S_RESLN reads the residual pair
+    // rows (2 N halves) at row stride ldr and writes pair rows at row stride ldc; wscale_inv: device scalar, the inverse of the
+    // power of two the B operand (the weight) was stored with, or null (1)
     int ldr;
+    const float *wscale_inv;
     int n_split;         // 2: N-split tile order (gemm256_f16.hip: tile_of_block; desc / split kernels only, N / 256 even); else 0
     int debug_mode;      // ance_debug_gemm ablations: 1 = no loads after tile 0, 2 = no MFMA, 4 = all blocks load tile (0,0)
 };

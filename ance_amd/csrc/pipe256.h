@@ -50,6 +50,9 @@ constexpr int PIPE_BUF_HALVES = 4 * PIPE_HALF_HALVES;  // A0 A1 B0 B1: 64 KiB
 constexpr size_t PIPE_LDS_BYTES = (size_t)2 * PIPE_BUF_HALVES * sizeof(_Float16);
 
 #define PIPE_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+#ifndef PIPE_PAIR3_STAGE_GAP
+#define PIPE_PAIR3_STAGE_GAP 2  // MFMA pairs between two LDS-DMA pieces of a PAIR3 phase (1: as the plain schedule)
+#endif
 
 // Row of the 256-row operand tile held at row r of half-tile h.
 __device__ __forceinline__ int pipe_a_tile_row(int h, int r) { return (((r >> 6) * 2 + h) << 6) + (r & 63); }
@@ -123,13 +126,25 @@ struct PipeSrcSplit {
 //        retired before the barrier that precedes its read.
 //   WAR  as above: a half-tile last read in phase p is restaged in the MFMA half-phase of phase p+1 at the earliest
 //        (A0 / B0 / B1 read in P0 of tile t, restaged in P1 of tile t; A1 read in P1 of tile t, restaged in P0 of t+1).
-template <class SRC, bool DBG = false, bool KEEP_B0 = false, bool COARSE = false>
+// PAIR3 (needs COARSE; the split GEMM, round 5): both operands are BLOCKED pair rows (common.h), so the 64 halves of an LDS row are
+//   [hi k 0..15 | hi k 16..31 | lo k 0..15 | lo k 16..31]  (fragment index s = 0..3)
+// and a K-tile is a 32-deep k-slice of hi AND lo of both operands.  Staging, LDS reads, barriers and waits are those of the
+// coarse schedule; only the products change: per output quadrant and k-step j the three MFMAs  hi_j x hi_j,  lo_j x hi_j,
+// hi_j x lo_j  (fragment pairs (j, j), (j + 2, j), (j, j + 2)) into the same accumulator -- 24 MFMAs per phase instead of 16,
+// i.e. per MFMA two thirds of the LDS-DMAs, ds_reads and barriers of three passes over [hi | lo'] rows (round 4).
+// MASKED: per-lane row masks on the fragments -- a lane whose keep_a bit y (A-tile row block y = 0..3 of its wave) / keep_b bit x
+// (B-tile row block x = 0, 1) is clear feeds zeros for that row, so the pass adds nothing to it.  Used by the folded GEMMs' second
+// pass over the lo halves of the token operand, which must touch the rows with a wide mean and ONLY those (a row's bits must not
+// depend on which other rows share its tile: gemm256_f16.hip).
+template <class SRC, bool DBG = false, bool KEEP_B0 = false, bool COARSE = false, bool PAIR3 = false, bool MASKED = false>
 struct Pipe256T {
     static_assert(!COARSE || KEEP_B0, "the coarse schedule keeps both B halves in registers");
+    static_assert(!PAIR3 || COARSE, "the pair products are built on the coarse schedule");
     SRC S;
     _Float16 *smem;
     int w, dbg = 0;
     int ra[2], rb, kx[4];  // per-lane read offsets (halves)
+    unsigned keep_a = 0xFu, keep_b = 0x3u;  // MASKED only
     f16x8 fa[2][4], fb[4], fbk[KEEP_B0 ? 4 : 1];
 
     __device__ __forceinline__ void init(_Float16 *smem_, int w_, int l) {
@@ -161,14 +176,20 @@ struct Pipe256T {
 #pragma unroll
         for (int s = 0; s < 4; ++s)
 #pragma unroll
-            for (int yy = 0; yy < 2; ++yy) fa[yy][s] = *reinterpret_cast<const f16x8 *>(base + ra[yy] + kx[s]);
+            for (int yy = 0; yy < 2; ++yy) {
+                fa[yy][s] = *reinterpret_cast<const f16x8 *>(base + ra[yy] + kx[s]);
+                if constexpr (MASKED)
+                    if (!((keep_a >> (2 * H + yy)) & 1u)) fa[yy][s] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            }
     }
     template <int H>
     __device__ __forceinline__ void read_b(int t) {
         const _Float16 *base = smem + (t & 1) * PIPE_BUF_HALVES + (2 + H) * PIPE_HALF_HALVES;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            const f16x8 v = *reinterpret_cast<const f16x8 *>(base + rb + kx[s]);
+            f16x8 v = *reinterpret_cast<const f16x8 *>(base + rb + kx[s]);
+            if constexpr (MASKED)
+                if (!((keep_b >> H) & 1u)) v = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
             if constexpr (KEEP_B0 && H == 0) fbk[s] = v;
             else fb[s] = v;
         }
@@ -236,30 +257,39 @@ struct Pipe256T {
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
+        constexpr int n_stage = (ST0 >= 0) + (ST1 >= 0) + (ST2 >= 0);
+        constexpr int types[3] = {ST0 >= 0 ? ST0 : 0, ST1 >= 0 ? ST1 : 0, ST2 >= 0 ? ST2 : 0};
+        // steps of two MFMAs (the two 32-row A fragments of this phase against one B fragment); PER = steps per B half
+        constexpr int PER = PAIR3 ? 6 : 4;
+        // PAIR3: (A fragment, B fragment) of step c -- hi_j x hi_j, lo_j x hi_j, hi_j x lo_j for j = 0, 1
+        constexpr int pa[6] = {0, 2, 0, 1, 3, 1}, pb[6] = {0, 0, 2, 1, 1, 3};
 #pragma unroll
-        for (int step = 0; step < 8; ++step) {
+        for (int step = 0; step < 2 * PER; ++step) {
             // P0 runs B-half0 first (it was read first); P1 runs B-half1 first (either order is fine for the result:
             // the two halves accumulate into different registers)
-            const int xx = (step >> 2) ^ YH, s = step & 3;
+            const int xx = (step / PER) ^ YH, c = step % PER;
+            const int sa = PAIR3 ? pa[c] : c, sb = PAIR3 ? pb[c] : c;
 #pragma unroll
             for (int yy = 0; yy < 2; ++yy) {
-                const f16x8 &bf = xx == 0 ? fbk[s] : fb[s];
+                const f16x8 &bf = xx == 0 ? fbk[sb] : fb[sb];
                 if (DBG && (dbg & 2)) {
-                    asm volatile("" ::"v"(bf), "v"(fa[yy][s]));
+                    asm volatile("" ::"v"(bf), "v"(fa[yy][sa]));
                 } else {
-                    acc[xx][2 * YH + yy] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf, fa[yy][s], acc[xx][2 * YH + yy], 0, 0, 0);
+                    acc[xx][2 * YH + yy] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf, fa[yy][sa], acc[xx][2 * YH + yy], 0, 0, 0);
                 }
             }
-            constexpr int n_stage = (ST0 >= 0) + (ST1 >= 0) + (ST2 >= 0);
-            if (step < 2 * n_stage) {  // one piece after each of the first 2 * n_stage MFMA pairs
+            // one LDS-DMA piece after each of the first 2 * n_stage MFMA pairs (PAIR3, STAGE_GAP = 2: after every second pair --
+            // the phase is half as long again, the pieces keep their distance in MFMA time)
+            constexpr int GAP = PAIR3 ? PIPE_PAIR3_STAGE_GAP : 1;
+            if (step % GAP == 0 && step / GAP < 2 * n_stage) {
+                const int pc = step / GAP;
                 __builtin_amdgcn_sched_barrier(0);
-                constexpr int types[3] = {ST0 >= 0 ? ST0 : 0, ST1 >= 0 ? ST1 : 0, ST2 >= 0 ? ST2 : 0};
-                if (step == 0) stage_piece<types[0], 0>(ts);
-                if (step == 1) stage_piece<types[0], 1>(ts);
-                if (step == 2) stage_piece<types[1], 0>(ts);
-                if (step == 3) stage_piece<types[1], 1>(ts);
-                if (step == 4) stage_piece<types[2], 0>(ts);
-                if (step == 5) stage_piece<types[2], 1>(ts);
+                if (pc == 0) stage_piece<types[0], 0>(ts);
+                if (pc == 1) stage_piece<types[0], 1>(ts);
+                if (pc == 2) stage_piece<types[1], 0>(ts);
+                if (pc == 3) stage_piece<types[1], 1>(ts);
+                if (pc == 4) stage_piece<types[2], 0>(ts);
+                if (pc == 5) stage_piece<types[2], 1>(ts);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }

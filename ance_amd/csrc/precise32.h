@@ -181,8 +181,8 @@ __global__ void __launch_bounds__(256) embed32_kernel(const int *tok_id, const i
 constexpr int P_KC = 128;
 constexpr size_t P_ATT_LDS = (size_t)2 * P_KC * 64 * sizeof(float);
 
-// ctx_pair != null (split mode, encoder.hip): the output row is written as an fp16 pair [hi (768) | lo' (768)],
-// lo' = fp16((v - hi) 2^11), the token operand of the split attention-output GEMM; cls_only: only query 0 of every sequence is
+// ctx_pair != null (split mode, encoder.hip): the output row is written as an fp16 pair row (common.h), the token operand of the
+// split attention-output GEMM; cls_only: only query 0 of every sequence is
 // computed and its row goes to row s (compact), as in attention.hip.
 __global__ void __launch_bounds__(256) attention32_kernel(const float *qkv, float *ctx, _Float16 *ctx_pair, int cls_only,
                                                           const int *seq_off, int n_heads) {
@@ -235,16 +235,11 @@ __global__ void __launch_bounds__(256) attention32_kernel(const float *qkv, floa
             const float inv = 1.0f / lsum;
             const size_t orow = cls_only ? (size_t)s : (size_t)(tok0 + qi);
             if (ctx_pair) {
-                _Float16 *ph = ctx_pair + orow * 1536 + h * 64;
+                _Float16 *ph = ctx_pair + orow * 1536;
 #pragma unroll
                 for (int d = 0; d < 64; d += 4) {
                     const f32x4 v = {acc[d] * inv, acc[d + 1] * inv, acc[d + 2] * inv, acc[d + 3] * inv};
-                    const f16x4 hi = cvt_f16x4_pinned(v);  // the stored hi and the hi of (v - hi) must be the same bits
-                    f16x4 lo;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) lo[e] = (_Float16)((v[e] - (float)hi[e]) * 2048.0f);
-                    *reinterpret_cast<f16x4 *>(ph + d) = hi;
-                    *reinterpret_cast<f16x4 *>(ph + 768 + d) = lo;
+                    pair_store4(v, ph, 768, h * 64 + d);  // the stored hi and the hi of (v - hi) are the same bits (common.h)
                 }
             } else {
                 float *op = ctx + orow * 768 + h * 64;

@@ -66,7 +66,7 @@ def _precision_env(env):
     if env is None:
         yield
         return
-    keys = ("ANCE_ENCODER_SPLIT", "ANCE_ENCODER_PRECISE")
+    keys = ("ANCE_ENCODER_SPLIT", "ANCE_ENCODER_PRECISE", "ANCE_ENCODER_FP16")
     saved = {k: os.environ.pop(k, None) for k in keys}
     os.environ.update(env)
     try:
@@ -78,16 +78,38 @@ def _precision_env(env):
                 os.environ[k] = saved[k]
 
 
+def precision_from_env(env=None):
+    """The mode a handle created now would run (the rule of csrc/encoder.hip: split_env / precise_env)."""
+    env = os.environ if env is None else env
+    if env.get("ANCE_ENCODER_PRECISE", "")[:1] == "1":
+        return "fp32"
+    s = env.get("ANCE_ENCODER_SPLIT", "")[:1]
+    if s == "1":
+        return "split"
+    if s == "0" or env.get("ANCE_ENCODER_FP16", "")[:1] == "1":
+        return "fp16"
+    return "split"
+
+
+def _written_through_raw_pointer(t):
+    """The library wrote ``t`` through its data pointer: bump the tensor's version counter, which is what
+    ``FlatIPIndex`` keys its search image on -- re-encoding into a buffer that was searched rebuilds the image."""
+    import torch
+    torch.autograd.graph.increment_version(t)
+
+
 class Encoder:
     """One transformer tower + (optional) ANCE head resident in HBM."""
 
-    PRECISIONS = {"fp16": {}, "split": {"ANCE_ENCODER_SPLIT": "1"}, "fp32": {"ANCE_ENCODER_PRECISE": "1"}}
+    PRECISIONS = {"fp16": {"ANCE_ENCODER_FP16": "1"}, "split": {"ANCE_ENCODER_SPLIT": "1"}, "fp32": {"ANCE_ENCODER_PRECISE": "1"}}
 
     def __init__(self, state_dict, arch=ARCH_ROBERTA, prefix="roberta.", has_head=True, pad_token_id=None,
                  ln_eps=None, max_seq_len=512, max_tokens=65536, device=None, precision=None):
-        """precision: None = whatever ANCE_ENCODER_SPLIT / ANCE_ENCODER_PRECISE say (include/ance_amd.h); "fp16" = the
-        default mode (fp16 MFMA operands, 3e-3), "split" = fp16-pair operands, fp32-grade (2e-5, ~2.6 x slower), "fp32" = fp32
-        operands (the audit path, ~9 x slower).  The library reads the mode when the handle is created."""
+        """precision: None = whatever the environment says (include/ance_amd.h) -- with nothing set that is "split", the
+        library's default: fp16-pair operands on the fp16 matrix cores, fp32-grade like the reference's own fp32 forward (2e-5;
+        the mode in which the refresh reproduces the reference's negative ids).  "fp16" = the fast mode (fp16 MFMA operands,
+        3e-3 on the embeddings, ~2.2 x the throughput; ANCE_ENCODER_FP16=1), "fp32" = fp32 operands (the audit path, ~3.5 x
+        slower than split; ANCE_ENCODER_PRECISE=1).  The library reads the mode when the handle is created."""
         import torch
         L = _lib.lib()
         if precision is not None and precision not in self.PRECISIONS:
@@ -96,8 +118,7 @@ class Encoder:
             self._create(L, torch, state_dict, arch, prefix, has_head, pad_token_id, ln_eps, max_seq_len, max_tokens, device)
 
     def _create(self, L, torch, state_dict, arch, prefix, has_head, pad_token_id, ln_eps, max_seq_len, max_tokens, device):
-        self.precision = "fp32" if os.environ.get("ANCE_ENCODER_PRECISE", "")[:1] == "1" else \
-            ("split" if os.environ.get("ANCE_ENCODER_SPLIT", "")[:1] == "1" else "fp16")
+        self.precision = precision_from_env()
         self.device = torch.device(device if device is not None else "cuda")
         n_layers = count_layers(state_dict, prefix)
         if n_layers == 0:
@@ -170,6 +191,7 @@ class Encoder:
             rc = _lib.lib().ance_encode_records(self._h, ctypes.c_void_p(records.data_ptr()), hl, n, Ltok, n_chunks,
                                                 ctypes.c_void_p(out.data_ptr()), _lib.current_stream_ptr())
         _lib.check(rc, "ance_encode_records")
+        _written_through_raw_pointer(out)
         return out
 
     def encode_ids(self, ids, lens, n_chunks=1, h_lens=None, out=None):
@@ -189,6 +211,7 @@ class Encoder:
                                             hl, n, Ltok, n_chunks, ctypes.c_void_p(out.data_ptr()),
                                             _lib.current_stream_ptr())
         _lib.check(rc, "ance_encode_ids")
+        _written_through_raw_pointer(out)
         return out
 
     # -- tensor path (seam B4) ---------------------------------------------------------------------
@@ -225,14 +248,22 @@ class AnceModel:
         max-over-chunks / 2-way log-softmax kernel ``ance_nll_forward``.  ``self.last_logits`` / ``self.last_loss_rows`` keep the
         per-triplet values of the last call (CUDA tensors)."""
         import torch
-        if input_ids_b is None and is_query:
+        if self.model_type == "dpr":
+            # BiEncoder.forward (model/models.py:260-271) has no is_query: with no second passage it returns BOTH towers' output
+            if input_ids_b is None:
+                return (self.query_emb(query_ids, attention_mask_q), self.body_emb(input_ids_a, attention_mask_a))
+        elif input_ids_b is None and is_query:
             return self.query_emb(query_ids, attention_mask_q)
-        if input_ids_b is None:
+        elif input_ids_b is None:
             return self.body_emb(query_ids, attention_mask_q)
         q = self.query_emb(query_ids, attention_mask_q).contiguous()
         a = self.body_emb(input_ids_a, attention_mask_a).contiguous()
         b = self.body_emb(input_ids_b, attention_mask_b).contiguous()
         n, d, chunks = q.shape[0], q.shape[1], self.chunks
+        if chunks > 1 and (input_ids_a.shape[1] // 512 != chunks or input_ids_b.shape[1] // 512 != chunks):
+            # the reference derives chunk_factor from the inputs (full_length // base_len, model/models.py:103-104)
+            raise ValueError("rdot_nll_multi_chunk: inputs of %d / %d tokens do not give the %d chunks this model was loaded for"
+                             % (input_ids_a.shape[1], input_ids_b.shape[1], chunks))
         ma = mb = None
         if chunks > 1:
             ma = attention_mask_a.to(q.device).reshape(n, chunks, -1)[:, :, 0].to(torch.float32).contiguous()

@@ -67,15 +67,11 @@ class FlatIPIndex:
         self._image = None
 
     def invalidate(self):
-        """Forget the search image of the added rows.  Call after the rows were rewritten THROUGH A RAW POINTER -- the
-        library's own ``Encoder.encode_records(out=...)`` / ``encode_ids(out=...)`` write that way, and such writes do not
-        bump the tensor version counter the image is keyed on: the filter would run on the stale fp16 rows while the exact
-        re-scoring reads the new ones, and true neighbours could be filtered out silently.  (The refresh job never reuses an
-        embedding buffer it has searched; benchmarks that re-encode into one buffer must call this.)  The old image is kept
-        alive until the searches already queued on it have finished."""
-        if getattr(self, "_image", None) is not None and self._image is not False:
-            import torch
-            self._image.record_stream(torch.cuda.current_stream(self.device))
+        """Forget the search image of the added rows.  Needed only after the rows were rewritten through a raw pointer by
+        code that does not bump the tensor's version counter (the image is keyed on it; the library's own
+        ``Encoder.encode_records(out=...)`` / ``encode_ids(out=...)`` do bump it): the filter would otherwise run on the stale
+        fp16 rows while the exact re-scoring reads the new ones, and true neighbours could be filtered out silently.  The old
+        image stays alive for the searches already queued on it (every search records its stream on the image it uses)."""
         self._image = None
 
     def _matrix(self):
@@ -110,9 +106,7 @@ class FlatIPIndex:
         # re-scoring reads the new ones
         key = (x.data_ptr(), x._version, n)
         if self._image is not None and self._image_key != key:
-            if self._image is not False:  # searches queued on another stream may still read the old image
-                self._image.record_stream(torch.cuda.current_stream(self.device))
-            self._image = None
+            self._image = None  # (searches queued on the old image keep it alive: search_device records their stream on it)
         if self._image is None:
             self._image_key = key
             self._image_event = None
@@ -145,6 +139,10 @@ class FlatIPIndex:
         if nq == 0:
             return D, I
         img = self._search_image(L, x)
+        if img is not None:
+            # at USE time and on the stream that uses it: the caching allocator must not hand the image's memory out again
+            # while this search is queued, whichever stream later drops or rebuilds the image
+            img.record_stream(torch.cuda.current_stream(self.device))
         need = L.ance_ip_topk_indexed_workspace_bytes(n, nq, self.dp, k)
         if need == 0:
             raise _lib.AnceLibraryError("ance_ip_topk: unsupported (n=%d, nq=%d, k=%d)" % (n, nq, k))

@@ -66,6 +66,11 @@ def parse():
     p.add_argument("--full-queries", type=int, default=N_TRAIN_QUERIES)
     p.add_argument("--full-dev-queries", type=int, default=6980)
     p.add_argument("--negative-sample", type=int, default=20)
+    p.add_argument("--skip-slice", action="store_true", help="skip the whole-refresh slice of the default run")
+    p.add_argument("--slice-passages", type=int, default=500000)
+    p.add_argument("--slice-queries", type=int, default=32768)
+    p.add_argument("--slice-dev-queries", type=int, default=6980)
+    p.add_argument("--slice-dir", type=str, default="/tmp/ance_slice")
     p.add_argument("--encoder-precision", type=str, default=None, choices=["fp16", "split", "fp32"],
                    help="--full only: the encoder arithmetic of the refresh (ance_amd.ann_data_gen --encoder_precision)")
     return p.parse_args()
@@ -95,14 +100,60 @@ def write_synthetic_cache(path, n, L, median, sigma, lo, seed, block=1 << 20):
     return time.perf_counter() - t0, tot / max(n, 1)
 
 
-def full_refresh(a):
-    """VERDICT r1 #3: the path the reference actually runs (drivers/run_ann_data_gen.py:231-336 over
-    utils/util.py:257-329), measured end to end on this box instead of extrapolated from one resident block."""
+def run_refresh(a, d, n_passages, n_train, n_dev, dist, dev, rank, precision):
+    """Write the tokenised caches of a synthetic collection to ``d`` (rank 0), then run ONE refresh on them with the product's
+    own job function (ance_amd.ann_data_gen.generate_new_ann: stream from disk, encode, search, host stage, files).
+    Returns (wall seconds of the refresh, per-phase seconds, preparation seconds, lines written, dev NDCG@10)."""
     import types
     import torch
     from safetensors.torch import save_file
     from ance_amd import ann_data_gen as adg
     from ance_amd import negatives
+    data, ckpt, outd = os.path.join(d, "data"), os.path.join(d, "checkpoint-1"), os.path.join(d, "out")
+    prep = {}
+    if rank == 0:
+        for sub in (data, ckpt, outd):
+            os.makedirs(sub, exist_ok=True)
+        prep["write_passages_s"], mean_p = write_synthetic_cache(os.path.join(data, "passages"), n_passages, a.seq_len, 70.0,
+                                                                 0.45, 8, 1)
+        prep["write_train_queries_s"], mean_q = write_synthetic_cache(os.path.join(data, "train-query"), n_train, 64, 9.0, 0.35, 4, 2)
+        prep["write_dev_queries_s"], _ = write_synthetic_cache(os.path.join(data, "dev-query"), n_dev, 64, 9.0, 0.35, 4, 3)
+        prep["mean_passage_len"], prep["mean_query_len"] = mean_p, mean_q
+        rng = np.random.default_rng(4)
+        with open(os.path.join(data, "train-qrel.tsv"), "w") as f:
+            pos = rng.integers(0, n_passages, size=n_train)
+            f.write("".join("%d\t%d\t1\n" % (q, p) for q, p in enumerate(pos.tolist())))
+        with open(os.path.join(data, "dev-qrel.tsv"), "w") as f:
+            pos = rng.integers(0, n_passages, size=n_dev)
+            f.write("".join("%d\t%d\t1\n" % (q, p) for q, p in enumerate(pos.tolist())))
+        save_file({k: v.contiguous() for k, v in random_init_roberta_base(torch, a.layers, seed=0).items()},
+                  os.path.join(ckpt, "model.safetensors"))
+    dist.barrier()
+    timings = {}
+    args = types.SimpleNamespace(data_dir=data, output_dir=outd, cache_dir=outd, inference=False, topk_training=a.topk,
+                                 negative_sample=a.negative_sample, ann_chunk_factor=1, ann_measure_topk_mrr=False,
+                                 model_type="rdot_nll", max_seq_length=a.seq_len, max_query_length=64, device=dev,
+                                 max_tokens=a.max_tokens, timings=timings, encoder_precision=precision)
+    import random
+    random.seed(0)
+    t0 = time.perf_counter()
+    train_pos, dev_pos = negatives.load_positive_ids(data)
+    prep["load_qrels_s"] = time.perf_counter() - t0
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    res = adg.generate_new_ann(args, 0, ckpt + "/", train_pos, dev_pos, 1, dist=dist)
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    lines = sum(1 for _ in open(os.path.join(outd, "ann_training_data_0"))) if rank == 0 else None
+    return wall, timings, prep, lines, (res[0] if res else None)
+
+
+def full_refresh(a):
+    """VERDICT r1 #3: the path the reference actually runs (drivers/run_ann_data_gen.py:231-336 over
+    utils/util.py:257-329), measured end to end on this box instead of extrapolated from one resident block."""
+    import torch
+    from ance_amd import ann_data_gen as adg
+    from ance_amd.encoder import precision_from_env
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count()
@@ -110,67 +161,52 @@ def full_refresh(a):
     dev = torch.device("cuda", local_rank)
     if world > 1:
         torch.distributed.init_process_group(backend=os.environ.get("ANCE_BENCH_BACKEND", "nccl"))
-    d = a.full_dir
-    data, ckpt, outd = os.path.join(d, "data"), os.path.join(d, "checkpoint-1"), os.path.join(d, "out")
-    prep = {}
-    if rank == 0:
-        for sub in (data, ckpt, outd):
-            os.makedirs(sub, exist_ok=True)
-        prep["write_passages_s"], mean_p = write_synthetic_cache(os.path.join(data, "passages"), a.n_passages, a.seq_len, 70.0,
-                                                                 0.45, 8, 1)
-        prep["write_train_queries_s"], mean_q = write_synthetic_cache(os.path.join(data, "train-query"), a.full_queries, 64,
-                                                                      9.0, 0.35, 4, 2)
-        prep["write_dev_queries_s"], _ = write_synthetic_cache(os.path.join(data, "dev-query"), a.full_dev_queries, 64, 9.0,
-                                                               0.35, 4, 3)
-        prep["mean_passage_len"], prep["mean_query_len"] = mean_p, mean_q
-        rng = np.random.default_rng(4)
-        with open(os.path.join(data, "train-qrel.tsv"), "w") as f:
-            pos = rng.integers(0, a.n_passages, size=a.full_queries)
-            f.write("".join("%d\t%d\t1\n" % (q, p) for q, p in enumerate(pos.tolist())))
-        with open(os.path.join(data, "dev-qrel.tsv"), "w") as f:
-            pos = rng.integers(0, a.n_passages, size=a.full_dev_queries)
-            f.write("".join("%d\t%d\t1\n" % (q, p) for q, p in enumerate(pos.tolist())))
-        save_file({k: v.contiguous() for k, v in random_init_roberta_base(torch, a.layers, seed=0).items()},
-                  os.path.join(ckpt, "model.safetensors"))
-    dist = adg.Dist()
-    dist.barrier()
-    timings = {}
-    args = types.SimpleNamespace(data_dir=data, output_dir=outd, cache_dir=outd, inference=False, topk_training=a.topk,
-                                 negative_sample=a.negative_sample, ann_chunk_factor=1, ann_measure_topk_mrr=False,
-                                 model_type="rdot_nll", max_seq_length=a.seq_len, max_query_length=64, device=dev,
-                                 max_tokens=a.max_tokens, timings=timings, encoder_precision=a.encoder_precision)
     import logging
-    import random
     logging.basicConfig(format="%(asctime)s %(name)s %(message)s", level=logging.INFO, stream=sys.stderr)
-    random.seed(0)
-    t0 = time.perf_counter()
-    train_pos, dev_pos = negatives.load_positive_ids(data)
-    t_qrels = time.perf_counter() - t0
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    res = adg.generate_new_ann(args, 0, ckpt + "/", train_pos, dev_pos, 1, dist=dist)
-    torch.cuda.synchronize()
-    wall = time.perf_counter() - t0
+    d = a.full_dir
+    mode = a.encoder_precision or precision_from_env()
+    wall, timings, prep, lines, ndcg = run_refresh(a, d, a.n_passages, a.full_queries, a.full_dev_queries, adg.Dist(), dev, rank, mode)
     if rank == 0:
-        lines = sum(1 for _ in open(os.path.join(outd, "ann_training_data_0")))
         enc_s = timings.get("encode_passages", 0.0)
-        mode = a.encoder_precision or ("fp32" if os.environ.get("ANCE_ENCODER_PRECISE", "")[:1] == "1" else
-                                       "split" if os.environ.get("ANCE_ENCODER_SPLIT", "")[:1] == "1" else "fp16")
         out = {"metric": "full_refresh_seconds", "value": wall, "unit": "s", "n_gpus": world, "higher_is_better": False,
-               "dtype": {"fp16": "f16", "split": "f16 pairs (fp32-grade)", "fp32": "f32"}[mode], "encoder_precision": mode, "data": "synthetic",
+               "dtype": DTYPE_OF[mode], "encoder_precision": mode, "data": "synthetic",
                "config": {"workload": "one ANN refresh: %d passages (seq_len %d, streamed from %s) + %d train queries "
                                       "(ann_chunk_factor 1) + %d dev queries, top-%d, %d negatives, roberta-base rdot_nll "
                                       "random init" % (a.n_passages, a.seq_len, d, a.full_queries, a.full_dev_queries, a.topk,
                                                        a.negative_sample)},
-               "phases_s": {k: round(v, 3) for k, v in timings.items()}, "load_qrels_s": round(t_qrels, 3),
+               "phases_s": {k: round(v, 3) for k, v in timings.items()},
                "prepare_s": {k: round(v, 3) for k, v in prep.items()},
                "passages_per_sec_measured": a.n_passages / enc_s if enc_s > 0 else None,
                "train_queries_per_sec_measured": a.full_queries / timings["search_train"] if timings.get("search_train") else None,
-               "lines_written": lines, "dev_ndcg": res[0] if res else None}
+               "lines_written": lines, "dev_ndcg": ndcg}
         print(json.dumps(out))
     if world > 1:
         torch.distributed.destroy_process_group()
 
+
+def refresh_slice(a, dist, dev, pps_step):
+    """A whole refresh INSIDE the default run, so that the streaming path (R5-R9: tokenised cache on disk ->
+    pinned ring -> HBM -> encoder) and the host stages (R15-R18: chunking, dev NDCG, negatives, writers) sit inside a time the
+    driver observes: a --slice-passages collection in the headline arithmetic, per-phase seconds, and the slice's own
+    passages/s beside the step benchmark's."""
+    import shutil
+    d = a.slice_dir
+    shutil.rmtree(d, ignore_errors=True)
+    try:
+        wall, timings, prep, lines, ndcg = run_refresh(a, d, a.slice_passages, a.slice_queries, a.slice_dev_queries, dist, dev, 0,
+                                                       HEADLINE_MODE)
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+    enc_s = timings.get("encode_passages", 0.0)
+    pps = a.slice_passages / enc_s if enc_s > 0 else None
+    return {"workload": "one ANN refresh of %d passages (seq_len %d) + %d train + %d dev queries, top-%d, %d negatives, caches "
+                        "streamed from %s, ance_amd.ann_data_gen.generate_new_ann, --encoder_precision %s"
+                        % (a.slice_passages, a.seq_len, a.slice_queries, a.slice_dev_queries, a.topk, a.negative_sample, d, HEADLINE_MODE),
+            "wall_s": wall, "phases_s": {k: round(v, 3) for k, v in timings.items()},
+            "prepare_s": {k: round(v, 3) for k, v in prep.items()},
+            "passages_per_sec": pps, "passages_per_sec_vs_step_benchmark": (pps / pps_step) if pps and pps_step else None,
+            "train_queries_per_sec": a.slice_queries / timings["search_train"] if timings.get("search_train") else None,
+            "lines_written": lines, "dev_ndcg": ndcg, "measured_in_this_run": True}
 
 
 def synthetic_records(rng, n, L):
@@ -222,7 +258,15 @@ def random_init_roberta_base(torch, n_layers, seed=0):
     return sd
 
 
-CURRENT_ROUND = "r04"  # counters and kernel traces under profiles/ are quoted only when they were taken on this round's tree
+CURRENT_ROUND = "r05"  # counters and kernel traces under profiles/ are quoted only when they were taken on this round's tree
+HEADLINE_MODE = "split"  # the library's default arithmetic: fp32-grade, the precision the reference computes in
+DTYPE_OF = {"split": "f16 pair operands on the fp16 MFMA, f32 accumulate (fp32-grade: <= 2e-5 from the reference's fp32 forward)",
+            "fp16": "f16", "fp32": "f32"}
+ARITHMETIC_OF = {
+    "split": "every GEMM operand an fp16 (hi, lo) pair, three fp16 MFMAs per k-step (hi hi + lo hi + hi lo) from four operand tiles staged "
+             "once, fp32 accumulation, fp32 softmax, exact erf GELU, fp32 head: fp32-grade (stated 2e-5, measured 5e-6 at 12 layers)",
+    "fp16": "fp16 MFMA operands, fp32 accumulation, LayerNorm folded into the GEMMs, residual stream as fp16 (hi, lo) pairs (stated 5e-3)",
+    "fp32": "fp32 operands on v_mfma_f32_32x32x2_f32, exact erf GELU, fp32 softmax (the reference's arithmetic; the audit path)"}
 KERNEL_OF_SPLIT = {"gemm_ffn1": "gemm256_split_kernel<9>", "gemm_qk": "gemm256_split_kernel<8>",
                    "gemm_attn_out": "gemm256_split_kernel<10>", "gemm_ffn2": "gemm256_split_kernel<10>"}
 KERNEL_OF_FP32 = {"gemm_ffn1": "gemm32_kernel<1>", "gemm_qk": "gemm32_kernel<0>", "gemm_attn_out": "gemm32_kernel<2>",
@@ -252,7 +296,9 @@ def pmc_traffic(leg, kernel):
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
             ent = json.load(f).get(leg, {}).get("gemm_res" if kernel in ("gemm_attn_out", "gemm_ffn2") else kernel)
-        return ent if ent and str(ent.get("round", "")).startswith(CURRENT_ROUND) else None  # never quote another round's counters
+        if not (ent and str(ent.get("round", "")).startswith(CURRENT_ROUND)):
+            return None  # never quote another round's counters
+        return dict(ent, measured_in_this_run=False, source="profiles/pmc_traffic.json (scripts/gpu_pmc.sh, rocprofv3 --pmc passes)")
     except Exception:
         return None
 
@@ -449,169 +495,133 @@ def main():
            "rccl_ranks": (torch.distributed.get_world_size() if dist_on else 1),
            "backend": (torch.distributed.get_backend() if dist_on else None),
            "steps": a.steps, "warmup": a.warmup, "ms_per_step": None, "higher_is_better": True, "scaling": "weak",
-           "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+           "vs_baseline": None, "dtype": DTYPE_OF[HEADLINE_MODE], "data": "synthetic",
            "config": {"workload": "MS MARCO passage %d x 768-d, roberta-base rdot_nll FirstP seq_len=%d, encode + "
                                   "brute-force IP top-%d (BASELINE configs[1])" % (a.n_passages, a.seq_len, a.topk),
                       "encode_block_per_gpu": a.encode_block, "query_block": a.query_block, "layers": a.layers,
                       "parallelism": "dp%d (corpus rows sharded, top-k all-to-all by query owner + merge)" % world}}
 
     # ------------------------------------------------------------------------------ encode leg --
+    # Three arithmetic modes of the same encoder on the same block.  The HEADLINE (top-level value / ms_per_step / dtype /
+    # roofline) is the library's default, the split mode: fp32-grade like the reference's own fp32 forward
+    # (model/models.py:149-157 has no .half()), so it is the precision-matched number.  The fp16 fast mode and the fp32 audit
+    # mode are reported beside it (`encode_fp16_fast`, `encode_fp32`), each with its own roofline and its measured distance
+    # from the headline mode's embeddings.
     if not a.skip_encode:
         try:
             sd = random_init_roberta_base(torch, a.layers, seed=0)
-            enc = Encoder(sd, ARCH_ROBERTA, "roberta.", True, max_seq_len=min(a.seq_len, 512),
-                          max_tokens=a.max_tokens, device=dev)
-            sd_for_probe = sd
             rng = np.random.default_rng(1234 + rank)
             rec, lens = synthetic_records(rng, a.encode_block, a.seq_len)
             rec_d = torch.from_numpy(rec).to(dev)
-            emb = torch.empty((a.encode_block, 768), dtype=torch.float32, device=dev)
             flops_alg = float(sum(169869312.0 * t + 36864.0 * t * t + 1179648.0 for t in lens.astype(np.float64)))
             flops_pad = a.encode_block * (169869312.0 * a.seq_len + 36864.0 * a.seq_len ** 2 + 1179648.0)
 
-            def step_enc():
-                enc.encode_records(rec_d, h_lens=lens, out=emb)
+            def measure_mode(mode, steps, kernels, peak, mfma_per_product, trace_label):
+                """K timed steps of `mode` on the product handle (two internal streams), then the same records on a single-stream
+                handle with the library's HIP events on: inside the timed region kernels of two micro-batches share the chip,
+                so a per-kernel duration is a property of the kernel only in the single-stream pass."""
+                enc = Encoder(sd, ARCH_ROBERTA, "roberta.", True, max_seq_len=min(a.seq_len, 512), max_tokens=a.max_tokens,
+                              device=dev, precision=mode)
+                assert enc.precision == mode
+                emb = torch.empty((a.encode_block, 768), dtype=torch.float32, device=dev)
 
-            for _ in range(max(a.warmup, 1)):
-                step_enc()
-            torch.cuda.synchronize()
-            dt = timed_steps(step_enc, a.steps, 0, dist_on, torch)
-            # Roofline pass.  The product overlaps consecutive micro-batches on two internal streams, so
-            # inside the timed region kernels of two micro-batches share the chip and a per-kernel
-            # duration is not a property of that kernel.  The same K steps are therefore repeated on a
-            # single-stream handle with the library's HIP events on (launch stream), kernels isolated.
-            os.environ["ANCE_ENCODER_STREAMS"] = "1"
-            enc1 = Encoder(sd_for_probe, ARCH_ROBERTA, "roberta.", True, max_seq_len=min(a.seq_len, 512),
-                           max_tokens=a.max_tokens, device=dev)
-            os.environ.pop("ANCE_ENCODER_STREAMS", None)
-            enc1.encode_records(rec_d, h_lens=lens, out=emb)
-            torch.cuda.synchronize()
-            _lib.profile_enable(True)
-            t1 = time.perf_counter()
-            for _ in range(a.steps):
-                enc1.encode_records(rec_d, h_lens=lens, out=emb)
-            torch.cuda.synchronize()
-            dt_iso = time.perf_counter() - t1
-            prof = _lib.profile_read()
-            _lib.profile_enable(False)
-            del enc1
-            pps = world * a.encode_block * a.steps / dt
+                def step():
+                    enc.encode_records(rec_d, h_lens=lens, out=emb)
+
+                for _ in range(max(a.warmup, 1)):
+                    step()
+                torch.cuda.synchronize()
+                dt = timed_steps(step, steps, 0, dist_on, torch)
+                os.environ["ANCE_ENCODER_STREAMS"] = "1"
+                try:
+                    enc1 = Encoder(sd, ARCH_ROBERTA, "roberta.", True, max_seq_len=min(a.seq_len, 512), max_tokens=a.max_tokens,
+                                   device=dev, precision=mode)
+                finally:
+                    os.environ.pop("ANCE_ENCODER_STREAMS", None)
+                emb1 = torch.empty_like(emb)
+                enc1.encode_records(rec_d, h_lens=lens, out=emb1)
+                torch.cuda.synchronize()
+                n_iso = steps if mode == HEADLINE_MODE else max(1, min(steps, 3))
+                _lib.profile_enable(True)
+                t1 = time.perf_counter()
+                for _ in range(n_iso):
+                    enc1.encode_records(rec_d, h_lens=lens, out=emb1)
+                torch.cuda.synchronize()
+                dt_iso = time.perf_counter() - t1
+                prof = _lib.profile_read()
+                _lib.profile_enable(False)
+                del enc1, emb1
+                gemm_cats = [c for c in ("gemm_qk", "gemm_vt", "gemm_attn_out", "gemm_ffn1", "gemm_ffn2") if prof[c]["count"]]
+                dom = max(gemm_cats, key=lambda c: prof[c]["ms"])
+                alg = prof[dom]["work"] / (prof[dom]["ms"] * 1e-3) / 1e12   # ALGORITHMIC TFLOP/s: 2 M N K per launch / its duration
+                all_ms = sum(prof[c]["ms"] for c in gemm_cats)
+                all_work = sum(prof[c]["work"] for c in gemm_cats)
+                t_ns = trace_avg_ns("%s_rocprofv3_%s_single_stream_kernel_stats.csv" % (CURRENT_ROUND, trace_label), kernels.get(dom, "?"))
+                fl = prof[dom]["work"] / max(prof[dom]["count"], 1)
+                pps = world * a.encode_block * steps / dt
+                roof = {"bound": "mfma", "kernel": "%s (%s)" % (kernels.get(dom, "?"), dom), "achieved": alg, "peak": peak,
+                        "unit": "TFLOP/s", "frac": alg / peak,
+                        "achieved_is": "algorithmic FLOPs (2 M N K of the launch) / average launch duration",
+                        "mfma_products_per_algorithmic_product": mfma_per_product,
+                        "frac_algorithmic": alg / peak, "frac_executed": alg * mfma_per_product / peak,
+                        "frac_from_profiles": {"value": (fl / (t_ns * 1e-9) / 1e12 / peak) if t_ns else None,
+                                               "measured_in_this_run": False,
+                                               "source": "profiles/%s_rocprofv3_%s_single_stream_kernel_stats.csv" % (CURRENT_ROUND, trace_label)},
+                        "traffic": pmc_traffic({"encode_fp16": "encode"}.get(trace_label, trace_label), dom),
+                        "timing": "HIP events on the launch stream, single-stream pass of %d steps (%.1f ms/step isolated vs %.1f "
+                                  "ms/step with the product's two internal streams)" % (n_iso, 1e3 * dt_iso / n_iso, 1e3 * dt / steps),
+                        "all_gemm_tflops": all_work / (all_ms * 1e-3) / 1e12 if all_ms > 0 else None,
+                        "by_kernel": {c: dict(ms_per_launch=v["ms"] / v["count"], launches=v["count"], total_ms=v["ms"],
+                                              tflops=(v["work"] / (v["ms"] * 1e-3) / 1e12) if v["ms"] > 0 and v["work"] > 0 else None)
+                                      for c, v in prof.items() if v["count"]}}
+                if peak != PEAK_F32_TF:
+                    roof["algorithmic_vs_fp32_mfma_peak"] = alg / PEAK_F32_TF
+                leg = {"value": pps, "unit": "passages/s", "ms_per_step": 1e3 * dt / steps, "steps": steps, "block": a.encode_block,
+                       "encoder_precision": mode, "dtype": DTYPE_OF[mode], "arithmetic": ARITHMETIC_OF[mode],
+                       "tokens_per_sec": pps * float(lens.mean()), "algorithmic_tflops": world * flops_alg * steps / dt / 1e12,
+                       "roofline": roof}
+                step()
+                torch.cuda.synchronize()
+                e = emb.clone()
+                del enc, emb
+                torch.cuda.empty_cache()
+                return leg, e
+
+            head, emb_head = measure_mode(HEADLINE_MODE, a.steps, KERNEL_OF_SPLIT, PEAK_F16_TF, 3.0, "encode_split")
+            pps = head["value"]
             out["value"] = pps
-            out["ms_per_step"] = 1e3 * dt / a.steps
-            gemm_cats = ["gemm_qk", "gemm_vt", "gemm_attn_out", "gemm_ffn1", "gemm_ffn2"]
-            dom = max(gemm_cats, key=lambda c: prof[c]["ms"])
-            by_kernel = {c: dict(ms_per_launch=(v["ms"] / v["count"]) if v["count"] else None, launches=v["count"],
-                                 total_ms=v["ms"], tflops=(v["work"] / (v["ms"] * 1e-3) / 1e12) if v["ms"] > 0 and v["work"] > 0 else None)
-                         for c, v in prof.items() if v["count"]}
-            ach = prof[dom]["work"] / (prof[dom]["ms"] * 1e-3) / 1e12 if prof[dom]["ms"] > 0 else None
-            all_gemm_ms = sum(prof[c]["ms"] for c in gemm_cats)
-            all_gemm_work = sum(prof[c]["work"] for c in gemm_cats)
-            # the same fraction from the committed kernel trace of this round (profiles/): FLOPs of one launch / its average
-            # duration in the single-stream rocprofv3 --stats CSV
-            t_ns = trace_avg_ns("%s_rocprofv3_encode_single_stream_kernel_stats.csv" % CURRENT_ROUND, KERNEL_OF.get(dom, "?"))
-            flop_launch = prof[dom]["work"] / max(prof[dom]["count"], 1)
-            out["roofline"] = {"bound": "mfma", "kernel": "%s (%s)" % (KERNEL_OF.get(dom, "gemm256_f16_desc_kernel"), dom), "achieved": ach,
-                               "peak": PEAK_F16_TF, "unit": "TFLOP/s", "frac": (ach / PEAK_F16_TF) if ach else None,
-                               "frac_from_profiles": (flop_launch / (t_ns * 1e-9) / 1e12 / PEAK_F16_TF) if t_ns else None,
-                               "traffic": pmc_traffic("encode", dom),
-                               "timing": "HIP events on the launch stream, single-stream pass of the same %d steps "
-                                         "(%.1f ms/step isolated vs %.1f ms/step overlapped)" % (a.steps, 1e3 * dt_iso / a.steps, 1e3 * dt / a.steps),
-                               "all_gemm_tflops": all_gemm_work / (all_gemm_ms * 1e-3) / 1e12 if all_gemm_ms > 0 else None,
-                               "by_kernel": by_kernel}
-            out["encode"] = {"passages_per_sec": pps, "tokens_per_sec": pps * float(lens.mean()),
-                             "mean_len": float(lens.mean()),
-                             "algorithmic_tflops": world * flops_alg * a.steps / dt / 1e12,
-                             "padded_equiv_tflops": world * flops_pad * a.steps / dt / 1e12,
-                             "end_to_end_mfma_frac": world * flops_alg * a.steps / dt / 1e12 / (PEAK_F16_TF * world),
+            out["ms_per_step"] = head["ms_per_step"]
+            out["dtype"] = head["dtype"]
+            out["encoder_precision"] = HEADLINE_MODE
+            out["roofline"] = head["roofline"]
+            out["encode"] = {"passages_per_sec": pps, "tokens_per_sec": head["tokens_per_sec"], "mean_len": float(lens.mean()),
+                             "arithmetic": head["arithmetic"], "algorithmic_tflops": head["algorithmic_tflops"],
+                             "padded_equiv_tflops": world * flops_pad * a.steps / (head["ms_per_step"] * 1e-3 * a.steps) / 1e12,
+                             "end_to_end_mfma_frac": head["algorithmic_tflops"] / (PEAK_F16_TF * world),
                              "hbm_min_bytes_per_passage": 4 + 4 * a.seq_len + 3072,
                              "full_corpus_seconds_est": N_PASSAGES / pps}
-            # ---- the two fp32-grade modes beside the default, as first-class measurements: the same block, the same K
-            # steps, their own roofline (single-stream pass with the library's HIP events), and how far the default's
-            # fp16-operand embeddings are from each on the same records (the stated tolerance, measured live)
-            # (single-GPU runs only: the multi-GPU runs are the driver's scaling curve of `value`, and the audit path would
+            # (single-GPU runs only: the multi-GPU runs are the driver's scaling curve of `value`, and the other two modes would
             # double their length)
             if not a.skip_precise and world == 1:
-                enc.encode_records(rec_d, h_lens=lens, out=emb)
-                torch.cuda.synchronize()
-                emb_default = emb.clone()
-                modes = {}
-                for label, env, kernels, peak in (("encode_split", "ANCE_ENCODER_SPLIT", KERNEL_OF_SPLIT, PEAK_F16_TF),
-                                                  ("encode_fp32", "ANCE_ENCODER_PRECISE", KERNEL_OF_FP32, PEAK_F32_TF)):
-                    os.environ[env] = "1"
-                    try:
-                        encp = Encoder(sd_for_probe, ARCH_ROBERTA, "roberta.", True, max_seq_len=min(a.seq_len, 512),
-                                       max_tokens=a.max_tokens, device=dev)
-                        os.environ["ANCE_ENCODER_STREAMS"] = "1"
-                        encp1 = Encoder(sd_for_probe, ARCH_ROBERTA, "roberta.", True, max_seq_len=min(a.seq_len, 512),
-                                        max_tokens=a.max_tokens, device=dev)
-                    finally:
-                        os.environ.pop(env, None)
-                        os.environ.pop("ANCE_ENCODER_STREAMS", None)
-                    embp = torch.empty_like(emb)
-
-                    def step_mode():
-                        encp.encode_records(rec_d, h_lens=lens, out=embp)
-
-                    step_mode()
-                    torch.cuda.synchronize()
-                    # the same K steps as the default leg; the 9 x slower audit path is capped at 8 steps (2.2 s each) so that a
-                    # driver run with a large K still finishes within minutes -- the JSON carries the count that was timed
-                    steps_m = a.steps if label == "encode_split" else min(a.steps, 8)
-                    dtm = timed_steps(step_mode, steps_m, 0, dist_on, torch)
-                    n_iso = max(1, min(a.steps, 3))
-                    encp1.encode_records(rec_d, h_lens=lens, out=embp)
-                    torch.cuda.synchronize()
-                    _lib.profile_enable(True)
-                    for _ in range(n_iso):
-                        encp1.encode_records(rec_d, h_lens=lens, out=embp)
-                    torch.cuda.synchronize()
-                    profm = _lib.profile_read()
-                    _lib.profile_enable(False)
-                    step_mode()
-                    torch.cuda.synchronize()
-                    gcats = [c for c in ("gemm_qk", "gemm_attn_out", "gemm_ffn1", "gemm_ffn2") if profm[c]["count"]]
-                    domm = max(gcats, key=lambda c: profm[c]["ms"])
-                    alg = profm[domm]["work"] / (profm[domm]["ms"] * 1e-3) / 1e12
-                    passes = 3.0 if label == "encode_split" else 1.0  # MFMA passes per algorithmic product
-                    t_ns = trace_avg_ns("%s_rocprofv3_%s_single_stream_kernel_stats.csv" % (CURRENT_ROUND, label), kernels.get(domm, "?"))
-                    fl = profm[domm]["work"] / max(profm[domm]["count"], 1)
-                    diff = (emb_default - embp).abs()
-                    pps_m = world * a.encode_block * steps_m / dtm
-                    modes[label] = {
-                        "value": pps_m, "unit": "passages/s", "ms_per_step": 1e3 * dtm / steps_m, "steps": steps_m,
-                        "block": a.encode_block,
-                        "algorithmic_tflops": world * flops_alg * steps_m / dtm / 1e12,
-                        "max_abs_vs_default": float(diff.max().item()), "mean_abs_vs_default": float(diff.mean().item()),
-                        "roofline": {"bound": "mfma", "kernel": "%s (%s)" % (kernels.get(domm, "?"), domm),
-                                     "achieved": alg * passes, "algorithmic": alg, "mfma_passes_per_product": passes,
-                                     "peak": peak, "unit": "TFLOP/s", "frac": alg * passes / peak,
-                                     "frac_from_profiles": (fl * passes / (t_ns * 1e-9) / 1e12 / peak) if t_ns else None,
-                                     "timing": "HIP events on the launch stream, single-stream pass of %d steps" % n_iso,
-                                     "by_kernel": {c: dict(ms_per_launch=v["ms"] / v["count"], launches=v["count"],
-                                                           algorithmic_tflops=(v["work"] / (v["ms"] * 1e-3) / 1e12) if v["work"] > 0 and v["ms"] > 0 else None)
-                                                   for c, v in profm.items() if v["count"]}}}
-                    if label == "encode_split":
-                        modes[label]["arithmetic"] = ("fp16 (hi, lo') pair operands, three fp16 MFMA passes per product, fp32 accumulation, fp32 "
-                                                      "softmax, exact erf GELU: fp32-grade (stated 2e-5); algorithmic TF above the 157.3 TF "
-                                                      "fp32-MFMA peak means it beats what fp32 operands could reach")
-                        modes[label]["algorithmic_vs_fp32_mfma_peak"] = alg / PEAK_F32_TF
-                        emb_split = embp.clone()
-                    else:
-                        modes[label]["arithmetic"] = "fp32 operands on v_mfma_f32_32x32x2_f32, exact erf GELU, fp32 softmax (the reference's arithmetic; the audit path)"
-                        if "encode_split" in modes:
-                            modes["encode_split"]["max_abs_vs_fp32_mode"] = float((emb_split - embp).abs().max().item())
-                    del encp, encp1, embp
-                    torch.cuda.empty_cache()
-                out.update(modes)
+                fast, emb_fast = measure_mode("fp16", a.steps, KERNEL_OF, PEAK_F16_TF, 1.0, "encode_fp16")
+                d = (emb_fast - emb_head).abs()
+                fast["max_abs_vs_split"], fast["mean_abs_vs_split"] = float(d.max().item()), float(d.mean().item())
+                fast["speedup_vs_headline"] = fast["value"] / pps
+                out["encode_fp16_fast"] = fast
+                # the 3.5 x slower audit path is capped at 8 steps so that a driver run with a large K still finishes within
+                # minutes -- the leg carries the count that was timed
+                p32, emb_32 = measure_mode("fp32", min(a.steps, 8), KERNEL_OF_FP32, PEAK_F32_TF, 1.0, "encode_fp32")
+                d = (emb_32 - emb_head).abs()
+                p32["max_abs_vs_split"], p32["mean_abs_vs_split"] = float(d.max().item()), float(d.mean().item())
+                out["encode_fp32"] = p32
                 out["encoder_modes"] = {
-                    "default": {"operands": "fp16 MFMA operands, fp32 accumulation, LayerNorm folded into the GEMMs, residual stream as fp16 (hi, lo) pairs",
-                                "passages_per_sec": pps},
-                    "split (ANCE_ENCODER_SPLIT=1)": {"passages_per_sec": modes["encode_split"]["value"]},
-                    "fp32 (ANCE_ENCODER_PRECISE=1)": {"passages_per_sec": modes["encode_fp32"]["value"]},
-                    "max_abs_default_vs_fp32": modes["encode_fp32"]["max_abs_vs_default"],
-                    "mean_abs_default_vs_fp32": modes["encode_fp32"]["mean_abs_vs_default"]}
-                del emb_default
-            del enc, rec_d, emb, sd_for_probe
+                    "split (default; headline)": {"passages_per_sec": pps},
+                    "fp16 (ANCE_ENCODER_FP16=1 / --encoder_precision fp16)": {"passages_per_sec": fast["value"],
+                                                                              "max_abs_vs_split": fast["max_abs_vs_split"]},
+                    "fp32 (ANCE_ENCODER_PRECISE=1 / --encoder_precision fp32)": {"passages_per_sec": p32["value"],
+                                                                                 "max_abs_vs_split": p32["max_abs_vs_split"]}}
+                del emb_fast, emb_32
+            del emb_head, rec_d
             torch.cuda.empty_cache()
         except Exception as e:  # keep going: a bench line with the other leg is still informative
             import traceback
@@ -679,9 +689,10 @@ def main():
                                                     "1,536 per query-row pair)",
                                           "achieved": ach, "peak": PEAK_F16_TF, "unit": "TFLOP/s",
                                           "frac": (ach / PEAK_F16_TF) if ach else None,
-                                          "frac_from_profiles": (lambda t_: (2.0 * a.query_block * n_loc * 768 / (t_ * 1e-9) / 1e12 / PEAK_F16_TF)
-                                                                 if t_ and world == 1 else None)(
+                                          "frac_from_profiles": {"value": (lambda t_: (2.0 * a.query_block * n_loc * 768 / (t_ * 1e-9) / 1e12 / PEAK_F16_TF)
+                                                                           if t_ and world == 1 else None)(
                                               trace_avg_ns("%s_rocprofv3_search_kernel_stats.csv" % CURRENT_ROUND, "ip_topk_fast_kernel<false, false>")),
+                                              "measured_in_this_run": False, "source": "profiles/%s_rocprofv3_search_kernel_stats.csv" % CURRENT_ROUND},
                                           "traffic": traffic,
                                           "ms_per_launch": scan["ms"] / n_scan,
                                           "rescore_ms_per_launch": resc["ms"] / max(resc["count"], 1),
@@ -727,6 +738,15 @@ def main():
             traceback.print_exc()
             errors["search"] = repr(e)
 
+    # --------------------------------------------------------------------- whole-refresh slice --
+    if world == 1 and not a.skip_slice and not a.skip_encode and out.get("value"):
+        try:
+            out["full_refresh_slice"] = refresh_slice(a, dist, dev, out["value"])
+        except Exception as e:
+            import traceback
+            traceback.print_exc()
+            errors["full_refresh_slice"] = repr(e)
+
     # ---------------------------------------------------------------------------- CPU baseline --
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         try:
@@ -737,7 +757,7 @@ def main():
         except Exception as e:
             errors["cpu_baseline"] = repr(e)
     try:  # measured by tests/test_gpu_retrieval.py on an MI355X (fp16-operand encoder vs the fp32 reference arithmetic)
-        src = next(n for n in ("r04_retrieval_agreement.json", "r03_retrieval_agreement.json", "r02_retrieval_agreement.json")
+        src = next(n for n in ("r05_retrieval_agreement.json", "r04_retrieval_agreement.json")
                    if os.path.exists(os.path.join(ROOT, "profiles", n)))
         with open(os.path.join(ROOT, "profiles", src)) as f:
             ra = json.load(f)
@@ -748,7 +768,8 @@ def main():
             out["retrieval_agreement"]["fp32_mode"] = {k_: ra["precise_mode"][k_] for k_ in keys}
         if "split_mode" in ra:
             out["retrieval_agreement"]["split_mode"] = {k_: ra["split_mode"][k_] for k_ in keys}
-        out["retrieval_agreement"]["source"] = "profiles/%s (tests/test_gpu_retrieval.py: both encoder modes against the fp32 oracle)" % src
+        out["retrieval_agreement"]["measured_in_this_run"] = False
+        out["retrieval_agreement"]["source"] = "profiles/%s (tests/test_gpu_retrieval.py: the three encoder modes against the fp32 oracle)" % src
     except Exception:
         pass
     if errors:

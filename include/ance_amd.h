@@ -38,7 +38,8 @@ extern "C" {
 #define ANCE_E_LAUNCH (-3)    /* HIP reported a launch error */
 #define ANCE_E_NOMEM (-4)
 
-#define ANCE_ABI_VERSION 3  /* 3: + ance_nll_forward, ance_search_bad_image_calls, ance_debug_gemm_split; split encoder mode */
+#define ANCE_ABI_VERSION 4  /* 4: blocked pair rows in the split mode (ance_pair_layout; ance_debug_gemm_split + d_wscale_inv); 3: + ance_nll_forward,
+                               ance_search_bad_image_calls, ance_debug_gemm_split; split encoder mode */
 int ance_abi_version(void);
 /* last HIP error string seen by this library on the calling thread ("" if none) */
 const char *ance_last_error(void);
@@ -187,8 +188,9 @@ typedef struct AnceEncoder AnceEncoder;
  * error is at most sqrt(1 + 2^2) x the random-init figure.  Pre-LayerNorm values must stay below 65,504 (fp16 range).
  * Environment, read when a handle is created (the two size queries read ANCE_ENCODER_PRECISE / ANCE_ENCODER_SPLIT as well):
  *   ANCE_ENCODER_SPLIT=1     split mode: an fp32-GRADE result from the fp16 matrix cores -- every GEMM operand an fp16 pair
- *                            v = hi + lo' 2^-11, three MFMA passes per product (hi lo' + lo' hi, rescale, hi hi), fp32 softmax,
- *                            exact erf GELU, fp32 head; max |delta| 2e-5 (stated), ~3 x slower than the default
+ *                            v = hi + lo, three MFMAs per k-step (hi hi + lo hi + hi lo) from four operand tiles staged once, fp32
+ *                            softmax, exact erf GELU, fp32 head; max |delta| 2e-5 (stated).  What the Python layer selects by
+ *                            default (precision="split"): the reference runs its encoder in fp32
  *   ANCE_ENCODER_PRECISE=1   fp32 mode: fp32 operands on the fp32-input matrix cores, exact erf GELU, fp32 softmax -- the
  *                            reference's arithmetic (model/models.py:149-157); max |delta| 1e-5, ~9 x slower (the audit path)
  *   ANCE_GEMM_NSPLIT=0       FFN1 without the N-split tile order (A/B switch)
@@ -262,16 +264,23 @@ int ance_nll_forward(const float *d_q, const float *d_a, const float *d_b, const
                      int d, int chunks, float *d_logits, float *d_loss_rows, float *d_loss_mean, void *stream);
 
 /* Test hook: the SPLIT (fp32-grade) GEMM of the encoder with one of its epilogues.  acc[m][n] = sum_k a[m][k] b[n][k] with
- * a = a_hi + a_lo' 2^-11 (b likewise); d_a_pair [M, 2K] / d_b_pair [N, 2K] fp16 rows [hi (K) | lo' (K)]; (mu_m, r_m) = mean and
- * 1 / sqrt(var + ln_eps) of row m combined from d_part [M][12][2], the (mean, M2) of its twelve 64-column slices.
- *   epi 8   d_out fp32 [M, N]      = r_m (acc - mu_m vec1[n]) + bias[n]                             (vec1 = csum)
- *   epi 9   d_out fp16 pair [M, 2N] = split(gelu_erf(r_m (acc - mu_m vec1[n]) + bias[n]))
- *   epi 10  d_out fp16 pair [M, 2N] = split(acc + bias[n] + (res[m][n] - mu_m) r_m vec1[n] + vec2[n])   (vec1 = gamma, vec2 = beta,
+ * a = a_hi + a_lo (b likewise; the lo x lo products are left out); d_a_pair [M, 2K] / d_b_pair [N, 2K] fp16 PAIR ROWS -- 32-column
+ * blocks [hi (32) | lo (32)], lo = fp16(v - hi) unscaled: ance_pair_layout gives the positions; (mu_m, r_m) = mean and
+ * 1 / sqrt(var + ln_eps) of row m combined from d_part [M][12][2], the (mean, M2) of its twelve 64-column slices;
+ * w = *d_wscale_inv (device scalar; NULL: 1), the inverse of the power of two b was stored with.
+ *   epi 8   d_out fp32 [M, N]      = r_m (w acc - mu_m vec1[n]) + bias[n]                             (vec1 = csum)
+ *   epi 9   d_out fp16 pair [M, 2N] = pair(gelu_erf(r_m (w acc - mu_m vec1[n]) + bias[n]))
+ *   epi 10  d_out fp16 pair [M, 2N] = pair(w acc + bias[n] + (res[m][n] - mu_m) r_m vec1[n] + vec2[n])   (vec1 = gamma, vec2 = beta,
  *           res = d_res_pair [M, 2N] pair rows; N = 768), d_part_out [M][12][2] = slice statistics of the output rows
  * M, N multiples of 256, K of 64, >= 128. */
 int ance_debug_gemm_split(int epi, const void *d_a_pair, const void *d_b_pair, int M, int N, int K, const float *d_bias,
                           const float *d_vec1, const float *d_vec2, const float *d_part, float ln_eps, const void *d_res_pair,
-                          void *d_out, float *d_part_out, void *stream);
+                          void *d_out, float *d_part_out, const float *d_wscale_inv, void *stream);
+
+/* Layout of the split mode's pair rows (for tests and tools that build or read them): column n of a W-wide fp32 row has its hi
+ * half at *hi_col and its lo half at *lo_col of the 2 W-half pair row, lo = fp16((v - hi) * *lo_scale).  Product library:
+ * hi_col = 64 (n / 32) + n % 32, lo_col = hi_col + 32, lo_scale = 1. */
+void ance_pair_layout(int n, int W, int *hi_col, int *lo_col, float *lo_scale);
 
 /* Re-reads every ANCE_* tuning knob from the environment (they are otherwise read once per process).  For tests and
  * sweeps that change a knob between two calls; not thread-safe against concurrent searches. */

@@ -29,7 +29,7 @@ def test_library_loads_and_exports_everything():
     raw = ctypes.CDLL(_lib.LIB_PATH)
     for name in _declared_functions():
         assert hasattr(raw, name), name
-    assert L.ance_abi_version() == _lib.ABI_VERSION == 3
+    assert L.ance_abi_version() == _lib.ABI_VERSION == 4
     assert L.ance_last_error() is not None
 
 
@@ -60,7 +60,7 @@ def test_invalid_arguments_are_rejected_before_any_launch():
     assert rc == -1
     rc = L.ance_nll_forward(None, None, None, None, None, 4, 768, 1, None, None, None, None)
     assert rc == -1 and b"nll" in L.ance_last_error()
-    rc = L.ance_debug_gemm_split(8, None, None, 256, 256, 128, None, None, None, None, 1e-5, None, None, None, None)
+    rc = L.ance_debug_gemm_split(8, None, None, 256, 256, 128, None, None, None, None, 1e-5, None, None, None, None, None)
     assert rc == -1
 
 

@@ -40,7 +40,8 @@ def _job(rank, world, data, ckpt, out, port, L=64, max_tokens=16384, precision=N
         dist.destroy_process_group()
 
 
-def test_multi_rank_refresh_on_one_gpu(tmp_path):
+@pytest.mark.parametrize("precision", [None, "fp16"])  # None: the job's default = the split (fp32-grade) mode
+def test_multi_rank_refresh_on_one_gpu(tmp_path, precision):
     from safetensors.torch import save_file
     from oracle import encoder_ref, synth
     data = str(tmp_path / "data")
@@ -54,9 +55,9 @@ def test_multi_rank_refresh_on_one_gpu(tmp_path):
         out = str(tmp_path / ("w%d" % world))
         port = 29600 + (os.getpid() + world) % 2000
         if world == 1:
-            _job(0, 1, data, str(ckpt) + "/", out, port)
+            _job(0, 1, data, str(ckpt) + "/", out, port, 64, 16384, precision)
         else:
-            torch.multiprocessing.spawn(_job, args=(world, data, str(ckpt) + "/", out, port), nprocs=world, join=True)
+            torch.multiprocessing.spawn(_job, args=(world, data, str(ckpt) + "/", out, port, 64, 16384, precision), nprocs=world, join=True)
         outs[world] = {n: open(os.path.join(out, n)).read() for n in ("ann_training_data_0", "ann_ndcg_0")}
         assert outs[world]["ann_training_data_0"].count("\n") == 1500
     assert outs[2] == outs[1], "2 ranks"
@@ -66,7 +67,8 @@ def test_multi_rank_refresh_on_one_gpu(tmp_path):
 def test_two_rank_refresh_at_512_tokens(tmp_path):
     """BASELINE configs[2] in miniature: FirstP at seq_len 512 (the long-sequence attention path: 128 queries per round,
     K / V^T of up to 512 keys in LDS), the corpus sharded over two ranks that share cuda:0, per-shard lists exchanged by
-    query owner and merged -- files byte-identical to the single-rank run."""
+    query owner and merged -- files byte-identical to the single-rank run.  (fp16 fast mode; the split mode at 512 tokens is the
+    next test.)"""
     from safetensors.torch import save_file
     from oracle import encoder_ref, synth
     data = str(tmp_path / "data")
@@ -80,9 +82,9 @@ def test_two_rank_refresh_at_512_tokens(tmp_path):
         out = str(tmp_path / ("w%d" % world))
         port = 29650 + (os.getpid() + world) % 2000
         if world == 1:
-            _job(0, 1, data, str(ckpt) + "/", out, port, 512, 32768)
+            _job(0, 1, data, str(ckpt) + "/", out, port, 512, 32768, "fp16")
         else:
-            torch.multiprocessing.spawn(_job, args=(world, data, str(ckpt) + "/", out, port, 512, 32768), nprocs=world, join=True)
+            torch.multiprocessing.spawn(_job, args=(world, data, str(ckpt) + "/", out, port, 512, 32768, "fp16"), nprocs=world, join=True)
         outs[world] = {n: open(os.path.join(out, n)).read() for n in ("ann_training_data_0", "ann_ndcg_0")}
         assert outs[world]["ann_training_data_0"].count("\n") == 400
     assert outs[2] == outs[1]

@@ -16,7 +16,7 @@ def _write_cache(path, ids, lens):
     synth.write_cache(path, ids, lens)
 
 
-@pytest.mark.parametrize("precision,tol", [(None, 1e-2), ("split", 2e-5)])
+@pytest.mark.parametrize("precision,tol", [("fp16", 1e-2), (None, 2e-5)])  # None: the job's default = split (fp32-grade)
 def test_dpr_job_end_to_end(tmp_path, precision, tol):
     from ance_amd import ann_data_gen as adg
     from ance_amd import ann_data_gen_dpr as job

@@ -15,7 +15,12 @@ pytestmark = pytest.mark.gpu
 
 # Against the reference's own run of the same job, every line that differs must be EXPLAINED: both negative lists have to be
 # exact rankings of scores within the measured error of the fp64 truth (tests/test_gpu_config1.py: tau_needed) -- near-ties
-# of two different roundings of the same encoder, nothing else.  The counts are recorded, not thresholded.
+# of two different roundings of the same encoder, nothing else.  That criterion alone cannot fail for an encoder regression
+# (tau_G is measured on the embeddings under test), so the error is bounded INDEPENDENTLY as well: the jobs run the library's
+# default arithmetic (split, fp32-grade), whose embeddings must be within EMB_TOL of the fp64 truth and whose score error
+# within TAU_CAP, and a floor on the lines / negative sets identical to the reference's run stays in place.
+EMB_TOL = 5e-5   # stated tolerance of the split mode against fp32 is 2e-5; against fp64 the fp32 oracle itself is 3e-6 away
+TAU_CAP = 2e-3   # = tau_R, what the reference's own fp32 forward + BLAS scores get (7.6e-4 measured at 12 layers)
 
 
 from golden_util import golden_weights  # noqa: E402
@@ -90,6 +95,8 @@ def test_refresh_job_end_to_end(golden_dir, tmp_path):
         S64 = (q64 @ p64.T).cpu().numpy()
         tau_G = 1.0001 * chain_score_error(torch.from_numpy(p_emb), torch.from_numpy(train_q), S64)
         tau_R = 2e-3  # the reference's fp32 CPU forward + BLAS scores (tests/test_gpu_config1.py measures 7.6e-4 at 12 layers)
+        emb_err = max(float(np.abs(p_emb - p64.cpu().numpy()).max()), float(np.abs(train_q - q64.cpu().numpy()).max()))
+        assert emb_err <= EMB_TOL and tau_G <= TAU_CAP, (emb_err, tau_G)
         ref_lines = dict(l.split("\t", 1) for l in e["ann_training_data_0"].splitlines())
         got_lines = dict(l.split("\t", 1) for l in open(train_path).read().splitlines())
         assert set(ref_lines) == set(got_lines)
@@ -108,10 +115,11 @@ def test_refresh_job_end_to_end(golden_dir, tmp_path):
         os.makedirs(outd, exist_ok=True)
         with open(os.path.join(outd, "e2e_agreement.json"), "w") as f:
             json.dump({"identical_lines": same, "lines": len(ref_lines), "differing_lines_explained_by_near_ties": len(ref_lines) - same - len(unexplained),
-                       "unexplained": unexplained, "tau_G": tau_G, "abs_delta_ndcg": d_ndcg, "ndcg": nd["ndcg"],
+                       "unexplained": unexplained, "tau_G": tau_G, "max_abs_emb_vs_fp64": emb_err, "abs_delta_ndcg": d_ndcg, "ndcg": nd["ndcg"],
                        "ndcg_reference": e["ann_ndcg_0"]["ndcg"]}, f)
         assert not unexplained, unexplained
-        assert d_ndcg <= 0.03, d_ndcg  # dev lists of 20 queries: one near-tie swap at rank <= 10 moves NDCG@10 by ~0.01
+        assert same >= 0.8 * len(ref_lines), (same, len(ref_lines))
+        assert d_ndcg <= 0.02, d_ndcg  # dev lists of 20 queries: one near-tie swap at rank <= 10 moves NDCG@10 by ~0.01
 
     # the reference consumer's line parser accepts the file (data/msmarco_data.py:338-343)
     for line in open(train_path):
@@ -134,7 +142,7 @@ def test_maxp_refresh_job_end_to_end(golden_dir, tmp_path):
     1024 / 1536 tokens, so all-pad chunks (one identical vector) sit in the top-k lists.
     (a) the oracle's post-search pipeline on the embeddings the GPU produced writes byte-identical files;
     (b) against the reference's own run of the same job (RobertaDot_CLF_ANN_NLL_MultiChunk, fp32 CPU): dev NDCG and the
-        negative lists within what the fp16-operand encoder and the different row order of tied all-pad rows allow
+        negative lists within what two fp32-grade roundings of the encoder and the different row order of tied all-pad rows allow
         (reference rows: per batch of 16 one slab per chunk, drivers/run_ann_data_gen.py:183-186)."""
     from safetensors.torch import save_file
     from ance_amd import ann_data_gen as adg
@@ -215,6 +223,8 @@ def test_maxp_refresh_job_end_to_end(golden_dir, tmp_path):
         S64 = S64_rows.reshape(len(lens_q), n_docs, chunks).max(-1)             # a document's score = its best chunk
         tau_G = 1.0001 * chain_score_error(torch.from_numpy(p_emb), torch.from_numpy(train_q), S64_rows)
         tau_R = 2e-3
+        emb_err = max(float(np.abs(p_emb - p64.cpu().numpy()).max()), float(np.abs(train_q - q64.cpu().numpy()).max()))
+        assert emb_err <= EMB_TOL and tau_G <= TAU_CAP, (emb_err, tau_G)
         ref_lines = dict(l.split("\t", 1) for l in e["ann_training_data_0"].splitlines())
         got_lines = dict(l.split("\t", 1) for l in open(train_path).read().splitlines())
         assert set(ref_lines) == set(got_lines)
@@ -233,6 +243,8 @@ def test_maxp_refresh_job_end_to_end(golden_dir, tmp_path):
         with open(os.path.join(outd, "e2e_agreement_maxp.json"), "w") as f:
             json.dump({"identical_lines": int(same), "identical_negative_sets": int(same_sets), "lines": len(ref_lines),
                        "differing_lines_explained_by_near_ties": len(ref_lines) - int(same) - len(unexplained), "unexplained": unexplained,
-                       "tau_G": tau_G, "abs_delta_ndcg": d_ndcg, "ndcg": nd["ndcg"], "ndcg_reference": e["ann_ndcg_0"]["ndcg"]}, f)
+                       "tau_G": tau_G, "max_abs_emb_vs_fp64": emb_err, "abs_delta_ndcg": d_ndcg, "ndcg": nd["ndcg"],
+                       "ndcg_reference": e["ann_ndcg_0"]["ndcg"]}, f)
         assert not unexplained, unexplained
+        assert same_sets >= 0.85 * len(ref_lines), (same_sets, len(ref_lines))
         assert d_ndcg <= 0.07, d_ndcg  # 8 dev queries: one near-tie swap at rank <= 10 moves NDCG@10 by up to 0.06

@@ -69,17 +69,44 @@ def test_full_chip_shape_repeated(epi):
             epi, rep, int(bad.sum()), float(err.max()), torch.nonzero(bad)[:3].tolist())
 
 
+def _pair_layout(W):
+    """(hi_cols, lo_cols, lo_scale) of a W-wide pair row, from the library itself (product build: 32-column blocks [hi | lo], lo
+    unscaled; the round-4 A/B build: [hi (W) | lo' (W)], lo' = (v - hi) 2^11)."""
+    from ance_amd import _lib
+    L = _lib.lib()
+    hi, lo, sc = ctypes.c_int(), ctypes.c_int(), ctypes.c_float()
+    hc, lc = [], []
+    for n in range(W):
+        L.ance_pair_layout(n, W, ctypes.byref(hi), ctypes.byref(lo), ctypes.byref(sc))
+        hc.append(hi.value)
+        lc.append(lo.value)
+    return torch.tensor(hc, device="cuda"), torch.tensor(lc, device="cuda"), float(sc.value)
+
+
 def _pair(v):
+    """fp32 [R, W] -> (hi, lo) halves of the pair, lo = fp16((v - hi) lo_scale)"""
+    _, _, sc = _pair_layout(32)
     hi = v.half()
-    lo = ((v - hi.float()) * 2048.0).half()
+    lo = ((v - hi.float()) * sc).half()
     return hi, lo
 
 
+def _pair_rows(hi, lo):
+    """(hi, lo) [R, W] -> pair rows [R, 2 W] fp16 in the library's layout"""
+    R, W = hi.shape
+    hc, lc, _ = _pair_layout(W)
+    out = torch.zeros((R, 2 * W), dtype=torch.float16, device=hi.device)
+    out[:, hc] = hi
+    out[:, lc] = lo
+    return out.contiguous()
+
+
 def _unpair(p, n):
-    return p[:, :n].double() + p[:, n:].double() / 2048.0
+    hc, lc, sc = _pair_layout(n)
+    return p[:, hc].double() + p[:, lc].double() / sc
 
 
-def _run_split(epi, M, N, K, seed=0, zero_a_lo=False, zero_b_lo=False):
+def _run_split(epi, M, N, K, seed=0, zero_a_lo=False, zero_b_lo=False, wscale=1.0):
     """The split GEMM (three fp16 MFMA passes over pair operands) through its test hook with one of its three epilogues,
     against the same expression in fp64.  Returns (got, ref, scale): scale = the magnitude rounding errors are relative to."""
     from ance_amd import _lib
@@ -87,14 +114,16 @@ def _run_split(epi, M, N, K, seed=0, zero_a_lo=False, zero_b_lo=False):
     g = torch.Generator(device="cuda").manual_seed(seed)
     a = torch.randn((M, K), generator=g, device="cuda")
     b = torch.randn((N, K), generator=g, device="cuda") * 0.02
+    _, _, lo_sc = _pair_layout(32)
     ah, al = _pair(a)
-    bh, bl = _pair(b)
+    bh, bl = _pair(b * wscale)  # the weight operand is stored times a power of two (undone by *d_wscale_inv in the epilogue)
     if zero_a_lo:
         al.zero_()
     if zero_b_lo:
         bl.zero_()
-    ap = torch.cat([ah, al], dim=1).contiguous()
-    bp = torch.cat([bh, bl], dim=1).contiguous()
+    ap = _pair_rows(ah, al)
+    bp = _pair_rows(bh, bl)
+    winv = torch.tensor([1.0 / wscale], dtype=torch.float32, device="cuda")
     bias = torch.randn(N, generator=g, device="cuda")
     vec1 = torch.randn(N, generator=g, device="cuda")
     vec2 = torch.randn(N, generator=g, device="cuda")
@@ -104,17 +133,17 @@ def _run_split(epi, M, N, K, seed=0, zero_a_lo=False, zero_b_lo=False):
     part[:, :, 1] = 64.0 * (0.5 + torch.rand((M, 12), generator=g, device="cuda"))
     eps = 1e-5
     res = torch.randn((M, N), generator=g, device="cuda")
-    rp = torch.cat(_pair(res), dim=1).contiguous()
+    rp = _pair_rows(*_pair(res))
     out = torch.empty((M, N), dtype=torch.float32, device="cuda") if epi == 8 else torch.zeros((M, 2 * N), dtype=torch.float16, device="cuda")
     part_out = torch.zeros((M, N // 64, 2), device="cuda")
     P = lambda t: ctypes.c_void_p(t.data_ptr())
     rc = L.ance_debug_gemm_split(epi, P(ap), P(bp), M, N, K, P(bias), P(vec1), P(vec2), P(part), eps, P(rp), P(out), P(part_out),
-                                 _lib.current_stream_ptr())
+                                 P(winv), _lib.current_stream_ptr())
     _lib.check(rc, "ance_debug_gemm_split")
-    A = ah.double() + al.double() / 2048.0
-    B = bh.double() + bl.double() / 2048.0
+    A = ah.double() + al.double() / lo_sc
+    B = (bh.double() + bl.double() / lo_sc) / wscale
     acc = A @ B.t()
-    dropped = ((al.double() / 2048.0).abs() @ (bl.double() / 2048.0).abs().t())  # the lo x lo term the kernel leaves out
+    dropped = ((al.double() / lo_sc).abs() @ (bl.double() / lo_sc / wscale).abs().t())  # the lo x lo term the kernel leaves out
     m = part[:, :, 0].double()
     mu = m.mean(1)
     var = (part[:, :, 1].double() + 64.0 * (m - mu[:, None]) ** 2).sum(1) / 768.0
@@ -147,7 +176,7 @@ def test_split_gemm_is_fp32_grade(shape, variant):
     up in exactly one of them."""
     M, N, K = shape
     got, ref, scale, _, _ = _run_split(8, M, N, K, seed=7, zero_a_lo=variant in ("a_lo_zero", "both_lo_zero"),
-                                       zero_b_lo=variant in ("b_lo_zero", "both_lo_zero"))
+                                       zero_b_lo=variant in ("b_lo_zero", "both_lo_zero"), wscale=2.0 ** 17)
     rel = (got - ref).abs() / scale
     assert float(rel.max()) <= 5e-7, (variant, shape, float(rel.max()), torch.nonzero(rel > 5e-7)[:3].tolist())
 
@@ -159,10 +188,44 @@ def test_split_gemm_pair_epilogues(epi, shape):
     bias + LayerNorm(residual pair) -> pair + slice statistics (epi 10).  A pair carries 22 bits: 2^-22 of the value on top of
     the GEMM's own 5e-7."""
     M, N, K = shape
-    got, ref, scale, part, want_part = _run_split(epi, M, N, K, seed=11)
+    got, ref, scale, part, want_part = _run_split(epi, M, N, K, seed=11, wscale=2.0 ** 17 if shape[0] != 256 else 1.0)
     rel = (got - ref).abs() / scale
     assert float(rel.max()) <= 1e-6, (epi, shape, float(rel.max()), torch.nonzero(rel > 1e-6)[:5].tolist())
     if part is not None:
         dm = (part[..., 0] - want_part[..., 0]).abs()
         dq = (part[..., 1] - want_part[..., 1]).abs() / want_part[..., 1]
         assert float(dm.max()) <= 2e-6 and float(dq.max()) <= 2e-5, (float(dm.max()), float(dq.max()), torch.nonzero(dq > 2e-5)[:5].tolist())
+
+
+def test_mfma_keeps_f16_subnormals():
+    """The split mode's pair halves are unscaled: lo = fp16(v - hi) of an element below 2^-3 is an fp16 SUBNORMAL.  The scheme
+    needs the conversion to produce it and v_mfma_f32_32x32x16_f16 to multiply it (gfx90a flushed them; gfx942 / gfx950 do not).
+    A with hi = 0 and lo = j 2^-24 (subnormal for j < 1024), B = 1: every output must be the exact sum of the lo halves -- a
+    flushing matrix core would return 0."""
+    from ance_amd import _lib
+    L = _lib.lib()
+    _, _, lo_sc = _pair_layout(32)
+    if lo_sc != 1.0:
+        pytest.skip("round-4 A/B build: lo halves are scaled into the normal range")
+    M = N = 256
+    K = 128
+    j = (torch.arange(M * K, device="cuda").reshape(M, K) % 1023 + 1).float()
+    al = (j * 2.0 ** -24).half()
+    assert torch.equal(al.float(), j * 2.0 ** -24) and float(al.float().max()) < 2.0 ** -14  # exactly representable, all subnormal
+    ah = torch.zeros_like(al)
+    bh = torch.ones((N, K), dtype=torch.float16, device="cuda")
+    bl = torch.zeros_like(bh)
+    ap, bp = _pair_rows(ah, al), _pair_rows(bh, bl)
+    bias = torch.zeros(N, device="cuda")
+    csum = torch.zeros(N, device="cuda")
+    part = torch.zeros((M, 12, 2), device="cuda")
+    part[:, :, 1] = 64.0  # mean 0, variance 1 -> r = 1 / sqrt(1 + eps)
+    out = torch.empty((M, N), device="cuda")
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    rc = L.ance_debug_gemm_split(8, P(ap), P(bp), M, N, K, P(bias), P(csum), None, P(part), 0.0, None, P(out), None, None,
+                                 _lib.current_stream_ptr())
+    _lib.check(rc, "ance_debug_gemm_split")
+    want = al.double().sum(1)  # exact: 128 terms of at most 10 bits at one binade spacing
+    got = out.double()
+    assert float(want.min()) > 0
+    assert torch.equal(got, want[:, None].expand(M, N).float().double()), (float(got.abs().max()), float(want.max()))

@@ -100,14 +100,16 @@ def test_retrieval_agreement_fp16_operands_vs_fp32_reference(monkeypatch):
                     planted_found=float(np.mean(I16[:n_q // 2, 0] == pos[:n_q // 2])),
                     planted_found_fp32=float(np.mean(I32[:n_q // 2, 0] == pos[:n_q // 2])))
 
-    # default mode: fp16 MFMA operands (folded LayerNorm, fp16 (hi, lo) residual stream)
+    # fp16 fast mode: fp16 MFMA operands (folded LayerNorm, fp16 (hi, lo) residual stream)
     monkeypatch.delenv("ANCE_ENCODER_PRECISE", raising=False)
+    monkeypatch.setenv("ANCE_ENCODER_FP16", "1")
     res = agreement(*encode_all())
+    monkeypatch.delenv("ANCE_ENCODER_FP16", raising=False)
     # fp32 mode (csrc/precise32.h): what is left is the summation order of two fp32 implementations
     monkeypatch.setenv("ANCE_ENCODER_PRECISE", "1")
     res_p = agreement(*encode_all())
     monkeypatch.delenv("ANCE_ENCODER_PRECISE", raising=False)
-    # split mode (fp16 pair operands, three MFMA passes): fp32-grade at a third of the fp16 rate
+    # split mode, the library's default (fp16 pair operands, three MFMAs per k-step): fp32-grade
     monkeypatch.setenv("ANCE_ENCODER_SPLIT", "1")
     res_s = agreement(*encode_all())
     monkeypatch.delenv("ANCE_ENCODER_SPLIT", raising=False)

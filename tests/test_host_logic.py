@@ -165,11 +165,12 @@ def test_cli_flags_match_reference_names():
 
 # ---- native host stage (csrc/host_postsearch.hip) ------------------------------------------------
 def test_encoder_precision_flag():
-    """The one added flag: --encoder_precision {fp16, split, fp32} (default: whatever the environment says)."""
+    """The one added flag: --encoder_precision {fp16, split, fp32}; the default is the fp32-grade split mode (the reference runs
+    its encoder in fp32, drivers/run_ann_data_gen.py:158,176-180), fp16 is the opt-in fast mode."""
     from ance_amd import ann_data_gen as adg
     base = ["--data_dir", "d", "--training_dir", "t", "--init_model_dir", "i", "--model_type", "rdot_nll", "--output_dir", "o",
             "--cache_dir", "c"]
-    assert adg.get_arguments(base).encoder_precision is None
+    assert adg.get_arguments(base).encoder_precision == "split"
     assert adg.get_arguments(base + ["--encoder_precision", "split"]).encoder_precision == "split"
     with pytest.raises(SystemExit):
         adg.get_arguments(base + ["--encoder_precision", "bf16"])
@@ -184,6 +185,8 @@ def test_precision_env_context_restores_the_environment(monkeypatch):
     assert os.environ.get("ANCE_ENCODER_PRECISE") == "1" and "ANCE_ENCODER_SPLIT" not in os.environ
     with _precision_env(Encoder.PRECISIONS["fp16"]):
         assert "ANCE_ENCODER_PRECISE" not in os.environ and "ANCE_ENCODER_SPLIT" not in os.environ
+        assert os.environ.get("ANCE_ENCODER_FP16") == "1"
+    assert "ANCE_ENCODER_FP16" not in os.environ
     with _precision_env(None):
         assert os.environ.get("ANCE_ENCODER_PRECISE") == "1"
 
