@@ -88,6 +88,39 @@ class Dist:
         if self.on:
             self.dist.barrier()
 
+    def all_gather_scalars(self, v):
+        """Every rank's integer ``v`` in rank order (host-side object collective: tiny, once per search)."""
+        if not self.on or self.world == 1:
+            return [int(v)]
+        box = [None] * self.world
+        self.dist.all_gather_object(box, int(v))
+        return [int(b) for b in box]
+
+    # ``comm``: None, or a dict the caller installed -- every device collective is then bracketed by events on the stream it
+    # is issued on and ``comm_ms()`` adds them up per collective (bench.py --gpus N prints it)
+    comm = None
+
+    def _timed(self, name, t, fn):
+        if self.comm is None or not t.is_cuda:
+            return fn()
+        import torch
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r = fn()
+        e1.record()
+        self.comm.setdefault(name, []).append((e0, e1, t.numel() * t.element_size()))
+        return r
+
+    def comm_ms(self):
+        """{collective: {"ms": total, "calls": n, "bytes": payload bytes per rank}} of the collectives recorded since ``comm`` was
+        installed (synchronises the device)."""
+        import torch
+        if not self.comm:
+            return {}
+        torch.cuda.synchronize()
+        return {k: {"ms": sum(a.elapsed_time(b) for a, b, _ in v), "calls": len(v), "bytes": sum(n for _, _, n in v)}
+                for k, v in self.comm.items()}
+
     def all_gather_rows(self, t, per):
         """Concatenate per-rank row blocks (each padded to ``per`` rows) in rank order."""
         import torch
@@ -99,7 +132,7 @@ class Dist:
         if self._host_staged(pad):
             pad = pad.cpu()
         parts = [torch.empty_like(pad) for _ in range(self.world)]
-        self.dist.all_gather(parts, pad)
+        self._timed("all_gather", pad, lambda: self.dist.all_gather(parts, pad))
         return torch.cat(parts, dim=0).to(dev)
 
     def _host_staged(self, t):
@@ -117,7 +150,7 @@ class Dist:
         dev = t.device
         src = t.cpu() if self._host_staged(t) else t
         out = torch.empty_like(src)
-        self.dist.all_to_all_single(out, src)
+        self._timed("all_to_all", src, lambda: self.dist.all_to_all_single(out, src))
         out = out.to(dev)
         return out.view((self.world, t.shape[0] // self.world) + tuple(t.shape[1:]))
 
@@ -130,7 +163,7 @@ class Dist:
         dev = t.device
         src = t.cpu() if self._host_staged(t) else t
         parts = [torch.empty_like(src) for _ in range(self.world)] if self.rank == 0 else None
-        self.dist.gather(src, parts, dst=0)
+        self._timed("gather", src, lambda: self.dist.gather(src, parts, dst=0))
         return torch.cat(parts, dim=0).to(dev) if self.rank == 0 else None
 
     def broadcast_object(self, obj):
@@ -198,6 +231,12 @@ class HipEngine:
             self._index = (key, idx)
         return self._index[1].search_device(q.contiguous(), k)
 
+    def side_stream(self):
+        """Stream the exchange of a multi-rank search runs on (sharded_search), beside the scan on the caller's stream."""
+        if getattr(self, "_side", None) is None:
+            self._side = self.torch.cuda.Stream(device=self.device)
+        return self._side
+
     def release_index(self):
         """Frees the cached search image (call when the shard's embeddings are about to be replaced)."""
         self._index = None
@@ -213,30 +252,86 @@ class HipEngine:
         return self.torch.from_numpy(np.ascontiguousarray(a)).to(self.device)
 
 
+SEARCH_CHUNK = 32768  # queries per exchange step = the search kernels' launch chunk (csrc/ip_topk_fast.hip)
+
+
+def _pack_lists(D, I_local):
+    """(D fp32 [n, k], ids int32 [n, k]) -> one int32 [n, k, 2] buffer: the wire format of a top-k list (8 bytes per entry)."""
+    import torch
+    return torch.stack((D.contiguous().view(torch.int32), I_local), dim=-1).contiguous()
+
+
+def _unpack_lists(buf):
+    import torch
+    return buf[..., 0].contiguous().view(torch.float32), buf[..., 1]
+
+
 def sharded_search(engine, dist, x_local, row_base, q_all, k):
     """Exact top-k of ``q_all`` over the union of every rank's shard.  Every rank scans its shard for ALL queries; the
-    per-shard lists are then exchanged by QUERY OWNER -- rank j receives every rank's lists for queries
-    [j per, (j + 1) per) with one all-to-all and merges them under the canonical order (the reference's own
-    shard-search-then-merge: utils/eval_mrr.py:137-183) -- and rank 0 gathers the merged blocks.  Per rank that is
-    nq k 12 bytes received instead of world x as much with an all-gather, and nq / world merges instead of nq.
+    per-shard lists are then exchanged by QUERY OWNER -- rank j receives every rank's lists for its block of the queries with one
+    all-to-all and merges them under the canonical order (the reference's own shard-search-then-merge:
+    utils/eval_mrr.py:137-183) -- and rank 0 gathers the merged blocks.  Per rank that is nq k 8 bytes received instead of
+    world x as much with an all-gather, and nq / world merges instead of nq.
+
+    The exchange runs per launch chunk of ``SEARCH_CHUNK`` queries on a side stream: chunk i's all-to-all + merge + gather
+    overlap chunk i + 1's scan (with RCCL the collective synchronises with the stream it is issued on; gloo's host-staged
+    collectives are simply synchronous).  On the wire a list entry is (score fp32, LOCAL row id int32): the receiver adds the
+    sender's ``row_base`` (exchanged once), so ids travel in 4 bytes whatever the corpus size.
     Returns (D, I) on rank 0 and (None, None) elsewhere (only rank 0 post-processes)."""
-    D, I = engine.search(x_local, row_base, q_all, k)
     if dist.world == 1:
-        return D, I
+        return engine.search(x_local, row_base, q_all, k)
     import torch
-    nq = D.shape[0]
-    per = (nq + dist.world - 1) // dist.world
-    if per * dist.world != nq:  # empty lists for the padding queries
-        Dp = torch.full((per * dist.world, k), torch.finfo(torch.float32).min, dtype=D.dtype, device=D.device)
-        Ip = torch.full((per * dist.world, k), -1, dtype=I.dtype, device=I.device)
-        Dp[:nq] = D
-        Ip[:nq] = I
-        D, I = Dp, Ip
-    Dm, Im = engine.merge(dist.all_to_all_blocks(D), dist.all_to_all_blocks(I))
-    D_all, I_all = dist.gather_rows_to_root(Dm), dist.gather_rows_to_root(Im)
+    W, nq = dist.world, q_all.shape[0]
+    dev = q_all.device
+    on_gpu = q_all.is_cuda
+    bases = dist.all_gather_scalars(int(row_base))  # row_base of every rank, in rank order
+    base_t = torch.tensor(bases, dtype=torch.int64, device=dev).view(W, 1, 1)
+    main = torch.cuda.current_stream(dev) if on_gpu else None
+    side = engine.side_stream() if on_gpu and hasattr(engine, "side_stream") else None
+    out_D, out_I = [], []
+    chunk = int(os.environ.get("ANCE_SEARCH_CHUNK", SEARCH_CHUNK))  # (tests shrink it to cross many chunk borders)
+    for c0 in range(0, nq, chunk):
+        c1 = min(c0 + chunk, nq)
+        n = c1 - c0
+        D, I = engine.search(x_local, row_base, q_all[c0:c1], k)
+        per = (n + W - 1) // W
+
+        def exchange(D=D, I=I, n=n, per=per):
+            I_loc = torch.where(I >= 0, I - row_base, I).to(torch.int32)  # -1 (fewer than k rows) stays -1
+            buf = _pack_lists(D, I_loc)
+            if per * W != n:  # empty lists for the padding queries of the last owner blocks
+                padded = torch.empty((per * W, k, 2), dtype=torch.int32, device=buf.device)
+                padded[:n] = buf
+                padded[n:, :, 0] = torch.tensor(torch.finfo(torch.float32).min, dtype=torch.float32).view(torch.int32).item()
+                padded[n:, :, 1] = -1
+                buf = padded
+            Dp, Ip = _unpack_lists(dist.all_to_all_blocks(buf))                     # [W, per, k] each, [p] = rank p's lists
+            Ip = torch.where(Ip >= 0, Ip.to(torch.int64) + base_t, Ip.to(torch.int64))
+            Dm, Im = engine.merge(Dp, Ip)                                           # [per, k], global ids
+            Dg, Ig = dist.gather_rows_to_root(Dm), dist.gather_rows_to_root(Im)
+            if dist.rank == 0:
+                out_D.append(Dg[:n])
+                out_I.append(Ig[:n])
+
+        if side is not None:
+            ev = torch.cuda.Event()
+            ev.record(main)
+            with torch.cuda.stream(side):
+                side.wait_event(ev)
+                D.record_stream(side)
+                I.record_stream(side)
+                exchange()
+        else:
+            exchange()
+    if side is not None:
+        main.wait_stream(side)
     if dist.rank != 0:
         return None, None
-    return D_all[:nq], I_all[:nq]
+    D_all, I_all = torch.cat(out_D, dim=0), torch.cat(out_I, dim=0)
+    if side is not None:  # allocated under the side stream, used from here on by the caller's
+        D_all.record_stream(main)
+        I_all.record_stream(main)
+    return D_all, I_all
 
 
 def encode_collection(engine, dist, model, cache, is_query, chunks=1, r_begin=0, r_end=None):

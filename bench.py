@@ -650,9 +650,13 @@ def main():
                 step_search()
             torch.cuda.synchronize()
             _lib.profile_enable(True)
+            if dist_on:
+                dist.comm = {}  # every device collective of the timed steps bracketed by events on its stream (Dist._timed)
             dt = timed_steps(step_search, a.steps, 0, dist_on, torch)
             prof = _lib.profile_read()
             _lib.profile_enable(False)
+            comm = dist.comm_ms() if dist_on else {}
+            dist.comm = None
             qps = a.query_block * a.steps / dt
             scan, resc, fin = prof["ip_topk_scan"], prof["ip_topk_rescore"], prof["topk_finalize"]
             n_scan = max(scan["count"], 1)  # (the device-side conditional redo launches of the fast path are not profiled)
@@ -683,6 +687,10 @@ def main():
                              "ms_per_step": 1e3 * dt / a.steps, "dtype": "f16 filter + f32 exact re-score (results bit-identical to the f32 scan)", "scaling": "strong (corpus sharded)",
                              "rows_total": a.n_passages, "rows_per_gpu": n_loc, "sorted_and_valid": ok,
                              "full_train_queries_seconds_est": N_TRAIN_QUERIES / qps,
+                             "comm_ms_per_step": {k_: {"ms": v_["ms"] / a.steps, "calls": v_["calls"] // a.steps, "bytes_per_rank": v_["bytes"] // a.steps}
+                                                  for k_, v_ in comm.items()} if dist_on else None,
+                             "comm_note": "rank 0's collectives of one step (all-to-all of the per-shard lists by query owner, gather of the merged "
+                                          "blocks), issued on the exchange stream beside the next chunk's scan" if dist_on else None,
                              "search_image_build_ms": build_ms,
                              "roofline": {"bound": bound,
                                           "kernel": "ip_topk_fast_kernel (fp16 MFMA 32x32x16 filter; algorithmic FLOPs = 2 nq n d = "
@@ -772,6 +780,8 @@ def main():
         out["retrieval_agreement"]["source"] = "profiles/%s (tests/test_gpu_retrieval.py: the three encoder modes against the fp32 oracle)" % src
     except Exception:
         pass
+    if dist_on and out["rccl_ranks"] != a.gpus:
+        errors["ranks"] = "process group has %d ranks, --gpus %d" % (out["rccl_ranks"], a.gpus)
     if errors:
         out["errors"] = errors
     if dist_on:

@@ -94,6 +94,56 @@ def golden_encoder():
     return out
 
 
+def golden_encoder12():
+    """FULL DEPTH (12 layers) for the other two towers and for the long-sequence FirstP case: the reference's OWN
+    classes at the depth configs 3-5's numbers are quoted at.  Separate from golden_encoder so that the older fixtures stay
+    byte-stable."""
+    rng = np.random.default_rng(2025)
+    out = {}
+    # MaxP body encoder, RobertaDot_CLF_ANN_NLL_MultiChunk.body_emb (model/models.py:165-199): 6 documents straddling the chunk
+    # borders (511 / 512 / 513 / 1024 / 1025 tokens), one full document, all-pad chunks behind the short ones
+    sd = encoder_ref.det_state_dict(seed=31, n_layers=12, ln_jitter=0.1)
+    m = ref_harness.build_reference_model("rdot_nll_multi_chunk", n_layers=12, seed=0)
+    load_into(m, sd)
+    lens = np.array([2048, 1025, 1024, 513, 512, 511], dtype=np.int32)
+    ids = synth.make_records(rng, len(lens), 2048, lens.astype(np.int64))
+    with torch.no_grad():
+        emb = m.body_emb(torch.from_numpy(ids).long(), encoder_ref.mask_from_lengths(lens, 2048))
+    out["maxp12"] = dict(gen="det", seed=31, n_layers=12, ln_jitter=0.1, checksum=sd_checksum(sd))
+    np.savez_compressed(os.path.join(OUT, "encoder_maxp12.npz"), ids=ids, lens=lens, emb=emb.numpy())
+    del m
+
+    # DPR / BERT tower, HFBertEncoder (model/models.py:223-244): raw [CLS], L = 256
+    sd3 = encoder_ref.det_state_dict(kind="bert", seed=33, n_layers=12, vocab=30522, max_pos=512, head=False,
+                                        prefixes=("ctx_model.",), ln_jitter=0.1)
+    m3 = ref_harness.build_reference_model("bert", n_layers=12, seed=0)
+    load_into(m3, {k[len("ctx_model."):]: v for k, v in sd3.items()})
+    lens3 = np.array([256, 3, 100, 255, 64, 17, 1, 200, 129, 128], dtype=np.int32)
+    ids3 = rng.integers(1000, 30522, size=(len(lens3), 256)).astype(np.int32)
+    ids3[np.arange(len(lens3)), lens3 - 1] = 102
+    ids3[:, 0] = 101
+    ids3 = np.where(np.arange(256)[None, :] < lens3[:, None], ids3, 0).astype(np.int32)
+    with torch.no_grad():
+        t = torch.from_numpy(ids3).long()
+        emb3 = m3(t, (t != 0).long())[1]
+    out["bert12"] = dict(gen="det", seed=33, n_layers=12, ln_jitter=0.1, checksum=sd_checksum(sd3))
+    np.savez_compressed(os.path.join(OUT, "encoder_bert12.npz"), ids=ids3, lens=lens3, emb=emb3.numpy())
+    del m3
+
+    # FirstP at seq_len 512 (BASELINE configs[2]), RobertaDot_NLL_LN.body_emb (model/models.py:149-157): the 256-key borders of the
+    # long-sequence attention path
+    sd5 = encoder_ref.det_state_dict(seed=35, n_layers=12, ln_jitter=0.1)
+    m5 = ref_harness.build_reference_model("rdot_nll", n_layers=12, seed=0)
+    load_into(m5, sd5)
+    lens5 = np.array([1, 255, 256, 257, 511, 512], dtype=np.int32)
+    ids5 = synth.make_records(rng, len(lens5), 512, lens5.astype(np.int64))
+    with torch.no_grad():
+        emb5 = m5.body_emb(torch.from_numpy(ids5).long(), encoder_ref.mask_from_lengths(lens5, 512))
+    out["firstp12_L512"] = dict(gen="det", seed=35, n_layers=12, ln_jitter=0.1, checksum=sd_checksum(sd5))
+    np.savez_compressed(os.path.join(OUT, "encoder_firstp12_L512.npz"), ids=ids5, lens=lens5, emb=emb5.numpy())
+    return out
+
+
 def golden_postsearch():
     """GenerateNegativePassaageID / EvalDevQuery of the reference on seeded neighbour lists."""
     ref = ref_harness.load_reference()
@@ -442,7 +492,7 @@ def golden_metrics():
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    makers = dict(encoder=golden_encoder, postsearch=golden_postsearch, e2e=golden_end_to_end, e2e_maxp=golden_end_to_end_maxp,
+    makers = dict(encoder=golden_encoder, encoder12=golden_encoder12, postsearch=golden_postsearch, e2e=golden_end_to_end, e2e_maxp=golden_end_to_end_maxp,
                   config1=golden_config1, nll=golden_nll,
                   dpr=golden_dpr, preprocess=golden_preprocess, metrics=golden_metrics, dpr_preprocess=golden_dpr_preprocess)
     which = sys.argv[1:] or list(makers)  # `make_golden.py e2e_maxp` regenerates one piece and its manifest entry

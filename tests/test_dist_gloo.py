@@ -80,15 +80,19 @@ def _run(rank, world, data, out, port, chunks):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("chunks", [1, 2])
-def test_two_rank_refresh_equals_single_process(tmp_path, chunks):
+@pytest.mark.parametrize("chunks,world,search_chunk", [(1, 2, None), (2, 2, None), (1, 3, 5), (2, 2, 7)])
+def test_multi_rank_refresh_equals_single_process(tmp_path, monkeypatch, chunks, world, search_chunk):
+    """2 and 3 ranks; search_chunk: the exchange of sharded_search runs per launch chunk of queries (32,768 in production) --
+    5 / 7 make the 47 train and 13 dev queries cross many chunk borders, with last chunks that do not divide by the world size."""
     from oracle import synth
+    if search_chunk:
+        monkeypatch.setenv("ANCE_SEARCH_CHUNK", str(search_chunk))
     data = str(tmp_path / "data")
     synth.make_msmarco_like(data, n_passages=301, n_train=47, n_dev=13, L=32, Lq=16, seed=3, len_median=14)
     out1, out2 = str(tmp_path / "w1"), str(tmp_path / "w2")
     _run(0, 1, data, out1, 0, chunks)
     port = 29500 + (os.getpid() % 2000)
-    mp.spawn(_run, args=(2, data, out2, port, chunks), nprocs=2, join=True)
+    mp.spawn(_run, args=(world, data, out2, port, chunks), nprocs=world, join=True)
     for name in ("ann_training_data_1", "ann_ndcg_1"):
         assert open(os.path.join(out1, name)).read() == open(os.path.join(out2, name)).read(), name
     j = json.load(open(os.path.join(out2, "ann_ndcg_1")))

@@ -278,6 +278,39 @@ def test_full_depth_golden_of_reference(monkeypatch, golden_dir, mode, tol):
     assert np.isfinite(got).all() and d <= tol, d
 
 
+@pytest.mark.parametrize("mode,tol", [("fp16", ABS_TOL), ("split", 2e-5), ("fp32", 2e-5)])
+def test_full_depth_goldens_of_the_other_towers(golden_dir, mode, tol):
+    """12 layers against the reference's OWN classes for configs 3-5 (tests/golden/make_golden.py: golden_encoder12):
+    RobertaDot_CLF_ANN_NLL_MultiChunk.body_emb on documents straddling the 512-token chunk borders with all-pad chunks behind
+    them (model/models.py:165-199), HFBertEncoder at L = 256 (:223-244), RobertaDot_NLL_LN.body_emb at seq_len 512 with lengths
+    at the 256-key borders of the long-sequence attention path (:149-157) -- each arithmetic mode at its stated tolerance."""
+    from ance_amd.encoder import ARCH_BERT, ARCH_ROBERTA, AnceModel, Encoder
+    man = _manifest(golden_dir)["encoder12"]
+    rec = {}
+    g = np.load(os.path.join(golden_dir, "encoder_maxp12.npz"))
+    enc = Encoder(_weights(man["maxp12"]), ARCH_ROBERTA, "roberta.", True, max_seq_len=512, max_tokens=8192, precision=mode)
+    model = AnceModel("rdot_nll_multi_chunk", enc, chunks=4)
+    ids = torch.from_numpy(g["ids"]).cuda()
+    mask = (torch.arange(2048)[None, :] < torch.from_numpy(g["lens"])[:, None]).long().cuda()
+    e = model.module.body_emb(input_ids=ids.long(), attention_mask=mask).cpu().numpy()
+    rec["maxp12"] = float(np.abs(e - g["emb"]).max())
+    assert np.array_equal(e[1, 3], e[2, 2]) and np.array_equal(e[1, 3], e[5, 1])  # all-pad chunks: one vector
+    del enc, model
+    g = np.load(os.path.join(golden_dir, "encoder_bert12.npz"))
+    enc = Encoder(_weights(man["bert12"], kind="bert", vocab=30522, max_pos=512, head=False, prefixes=("ctx_model.",)), ARCH_BERT,
+                  "ctx_model.", False, max_seq_len=256, max_tokens=4096, precision=mode)
+    ids = torch.from_numpy(g["ids"]).cuda()
+    rec["bert12"] = float(np.abs(enc.embed(ids, (ids != 0).long()).cpu().numpy() - g["emb"]).max())
+    del enc
+    g = np.load(os.path.join(golden_dir, "encoder_firstp12_L512.npz"))
+    enc = Encoder(_weights(man["firstp12_L512"]), ARCH_ROBERTA, "roberta.", True, max_seq_len=512, max_tokens=2048, precision=mode)
+    got = enc.encode_ids(torch.from_numpy(g["ids"]).cuda(), torch.from_numpy(g["lens"]).cuda(), h_lens=g["lens"]).cpu().numpy()
+    rec["firstp12_L512"] = float(np.abs(got - g["emb"]).max())
+    with open(os.path.join(OUT, "encoder_parity.jsonl"), "a") as f:
+        f.write(json.dumps(dict(case="golden12_other_towers_%s" % mode, **rec)) + "\n")
+    assert all(np.isfinite(v) and v <= tol for v in rec.values()), rec
+
+
 def test_split_mode_against_oracle(monkeypatch):
     """ANCE_ENCODER_SPLIT=1: fp16-pair operands, three MFMA passes per product, fp32 softmax, exact erf GELU.  Stated
     tolerance 2e-5 on unit-variance rows against the fp32 oracle (12 layers, L = 128; 3 layers, L = 512; rows independent

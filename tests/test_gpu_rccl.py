@@ -47,6 +47,61 @@ def _rank(rank, world, port, out_path):
     dist.destroy_process_group()
 
 
+def _job_rank(rank, world, port, data, ckpt, out):
+    """One rank of a WHOLE refresh (ance_amd.ann_data_gen.generate_new_ann with the real HipEngine) over backend nccl, one device
+    per rank -- what `python -m torch.distributed.run ... -m ance_amd.ann_data_gen` runs (drivers/run_ann_data_gen.py:637-640)."""
+    import random
+    import types
+    sys.path.insert(0, ROOT)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    from ance_amd import ann_data_gen as adg
+    from ance_amd import negatives
+    dev = torch.device("cuda", rank if world > 1 else 0)
+    torch.cuda.set_device(dev)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    args = types.SimpleNamespace(data_dir=data, output_dir=out, cache_dir=out, inference=False, topk_training=100,
+                                 negative_sample=8, ann_chunk_factor=1, ann_measure_topk_mrr=False, model_type="rdot_nll",
+                                 max_seq_length=64, max_query_length=32, device=dev, max_tokens=16384, encoder_precision=None)
+    train_pos, dev_pos = negatives.load_positive_ids(data)
+    random.seed(4321)
+    d = adg.Dist()
+    assert d.world == world and d.rank == rank
+    res = adg.generate_new_ann(args, 0, ckpt, train_pos, dev_pos, 100, engine=adg.HipEngine(dev), dist=d)
+    assert (res is not None) == (rank == 0)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL needs one device per rank: fewer than 2 GPUs on this box")
+def test_refresh_job_over_rccl_equals_one_rank(tmp_path, monkeypatch):
+    """The whole job on 2 (up to 4) devices over RCCL against the same job on one: both output files byte for byte (SURVEY 8e:
+    results do not depend on the GPU count).  ANCE_SEARCH_CHUNK=512 makes the 1,500 train queries cross several exchange chunks, so
+    the side-stream overlap of sharded_search (chunk i's all-to-all + merge + gather under chunk i + 1's scan) really runs."""
+    from safetensors.torch import save_file
+    from oracle import encoder_ref, synth
+    monkeypatch.setenv("ANCE_SEARCH_CHUNK", "512")
+    data = str(tmp_path / "data")
+    synth.make_msmarco_like(data, n_passages=20000, n_train=1500, n_dev=301, L=64, Lq=32, seed=11, len_median=30)
+    sd = encoder_ref.random_state_dict(seed=5, n_layers=2, ln_jitter=0.1)
+    ckpt = tmp_path / "checkpoint-100"
+    ckpt.mkdir()
+    save_file({k: v.contiguous() for k, v in sd.items()}, str(ckpt / "model.safetensors"))
+    outs = {}
+    for world in (1, min(torch.cuda.device_count(), 4)):
+        out = str(tmp_path / ("w%d" % world))
+        port = 29800 + (os.getpid() + world) % 2000
+        torch.multiprocessing.spawn(_job_rank, args=(world, port, data, str(ckpt) + "/", out), nprocs=world, join=True)
+        outs[world] = {n: open(os.path.join(out, n)).read() for n in ("ann_training_data_0", "ann_ndcg_0")}
+        assert outs[world]["ann_training_data_0"].count("\n") == 1500
+    a, b = outs.values()
+    assert a == b
+
+
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL needs one device per rank: fewer than 2 GPUs on this box")
 def test_sharded_search_over_rccl(tmp_path):
     from oracle import search_ref, synth

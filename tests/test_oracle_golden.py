@@ -66,6 +66,33 @@ def test_encoder_bert_matches_reference(golden_dir):
     assert np.abs(emb.numpy() - g["emb"]).max() <= 2e-5
 
 
+def test_encoders_full_depth_other_towers_match_reference(golden_dir):
+    """12 layers for the other two towers and the long FirstP case (tests/golden/make_golden.py: golden_encoder12): the oracle
+    restatements against RobertaDot_CLF_ANN_NLL_MultiChunk.body_emb (model/models.py:165-199; documents straddling the chunk
+    borders, all-pad chunks), HFBertEncoder (:223-244, L = 256) and RobertaDot_NLL_LN.body_emb at L = 512 (:149-157; lengths
+    1, 255, 256, 257, 511, 512) -- the depth the numbers of BASELINE configs 3-5 are quoted at."""
+    man = _manifest(golden_dir)["encoder12"]
+    g = np.load(os.path.join(golden_dir, "encoder_maxp12.npz"))
+    sd = _weights(man["maxp12"])
+    with torch.no_grad():
+        emb = encoder_ref.rdot_nll_multi_chunk_body_emb(sd, torch.from_numpy(g["ids"]), encoder_ref.mask_from_lengths(g["lens"], 2048),
+                                                        n_layers=12)
+    assert emb.shape == (6, 4, 768) and np.abs(emb.numpy() - g["emb"]).max() <= 2e-5
+    e = g["emb"]  # all-pad chunks: one and the same vector, also at full depth
+    assert np.array_equal(e[1, 3], e[2, 2]) and np.array_equal(e[1, 3], e[5, 1]) and not np.array_equal(e[1, 3], e[1, 2])
+    g = np.load(os.path.join(golden_dir, "encoder_bert12.npz"))
+    sd = _weights(man["bert12"], kind="bert", vocab=30522, max_pos=512, head=False, prefixes=("ctx_model.",))
+    ids = torch.from_numpy(g["ids"])
+    with torch.no_grad():
+        emb = encoder_ref.bert_cls(sd, ids, (ids != 0).long(), "ctx_model.", n_layers=12)
+    assert np.abs(emb.numpy() - g["emb"]).max() <= 2e-5
+    g = np.load(os.path.join(golden_dir, "encoder_firstp12_L512.npz"))
+    sd = _weights(man["firstp12_L512"])
+    with torch.no_grad():
+        emb = encoder_ref.rdot_nll_ln_emb(sd, torch.from_numpy(g["ids"]), encoder_ref.mask_from_lengths(g["lens"], 512), n_layers=12)
+    assert np.abs(emb.numpy() - g["emb"]).max() <= 2e-5
+
+
 def _postsearch(golden_dir):
     g = np.load(os.path.join(golden_dir, "postsearch.npz"))
     with open(os.path.join(golden_dir, "postsearch.json")) as f:
