@@ -409,6 +409,9 @@ constexpr float GELU_Q[10] = {-1.0f, -1.627907395362854f, -0.918441653251648f, -
                               1.1468856428109575e-05f};
 __device__ __forceinline__ float gelu_exact(float x) {
 #pragma clang fp contract(off)
+#ifdef ANCE_GELU_ERFF  // A/B builds only (make variant NAME=erff DEFS=-DANCE_GELU_ERFF): round 4's library erff
+    return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+#endif
     const float z = __builtin_fminf(__builtin_fabsf(x) * 0.70710678118654752440f, 6.6f);
     float q = GELU_Q[9];
 #pragma unroll

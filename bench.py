@@ -516,6 +516,8 @@ def main():
             flops_alg = float(sum(169869312.0 * t + 36864.0 * t * t + 1179648.0 for t in lens.astype(np.float64)))
             flops_pad = a.encode_block * (169869312.0 * a.seq_len + 36864.0 * a.seq_len ** 2 + 1179648.0)
 
+            want_emb = not a.skip_precise and world == 1
+
             def measure_mode(mode, steps, kernels, peak, mfma_per_product, trace_label):
                 """K timed steps of `mode` on the product handle (two internal streams), then the same records on a single-stream
                 handle with the library's HIP events on: inside the timed region kernels of two micro-batches share the chip,
@@ -580,9 +582,11 @@ def main():
                        "encoder_precision": mode, "dtype": DTYPE_OF[mode], "arithmetic": ARITHMETIC_OF[mode],
                        "tokens_per_sec": pps * float(lens.mean()), "algorithmic_tflops": world * flops_alg * steps / dt / 1e12,
                        "roofline": roof}
-                step()
-                torch.cuda.synchronize()
-                e = emb.clone()
+                e = None
+                if want_emb:  # the mode's embeddings of the block, for the distance between the modes
+                    step()
+                    torch.cuda.synchronize()
+                    e = emb.clone()
                 del enc, emb
                 torch.cuda.empty_cache()
                 return leg, e

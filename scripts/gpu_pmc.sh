@@ -10,10 +10,10 @@ export TMPDIR=/tmp
 # one step, no fp32-mode sample, no second search leg, and counters only for the kernels a roofline is reported for: a pass
 # of the encode leg (~6 k dispatches) otherwise does not finish inside the 900 s limit
 S="python bench.py --skip-encode --no-cpu-baseline --skip-encoder-like --steps ${PMC_STEPS:-1} --warmup 1"
-E="python bench.py --skip-search --no-cpu-baseline --skip-precise --steps ${PMC_STEPS:-1} --warmup 1"
-for what in ${PMC_LEGS:-search encode}; do
-  cmd="$S"; [ $what = encode ] && cmd="$E"
-  [ $what = encode ] && export ANCE_ENCODER_STREAMS=1
+# legs: search | encode_split (the headline arithmetic since round 5) | encode (= the fp16 fast mode) | encode_fp32 (kernel trace only)
+for what in ${PMC_LEGS:-search encode_split}; do
+  cmd="$S"
+  if [ $what = encode ]; then cmd="python scripts/encode_mode_leg.py fp16"; export ANCE_ENCODER_STREAMS=1; fi
   if [ $what = encode_split ]; then cmd="python scripts/encode_mode_leg.py split"; export ANCE_ENCODER_STREAMS=1; fi
   if [ $what = encode_fp32 ]; then cmd="python scripts/encode_mode_leg.py fp32 1 4096"; export ANCE_ENCODER_STREAMS=1; fi
   rx="ip_topk_fast_kernel|rescore_kernel"; [ $what = encode ] && rx="gemm256_f16_desc_kernel|attention_kernel"
@@ -34,9 +34,9 @@ for what in ${PMC_LEGS:-search encode}; do
 done
 # ---- HBM traffic of the WHOLE encode step by counters (north_star: "rocprof evidences achieved HBM GB/s on the encode sweep"): every
 # kernel of the leg, a 4,096-passage block so that a counter pass (~500 dispatches) finishes, the same block timed untraced
-if [[ " ${PMC_LEGS:-search encode} " == *" encode "* ]]; then
+if [[ " ${PMC_LEGS:-search encode_split} " == *" encode_split "* ]]; then
   export ANCE_ENCODER_STREAMS=1
-  EA="python bench.py --skip-search --no-cpu-baseline --skip-precise --encode-block 4096 --steps 1 --warmup 1"
+  EA="python bench.py --skip-search --no-cpu-baseline --skip-precise --skip-slice --encode-block 4096 --steps 1 --warmup 1"
   echo "== untraced step, 4,096-passage block"
   timeout 300 $EA > gpurun_out/pmc/encode_all_plain.json 2> gpurun_out/pmc/encode_all_plain.err; echo "rc=$?"
   for c in FETCH_SIZE WRITE_SIZE; do
