@@ -182,7 +182,7 @@ class HipEngine:
     """Device operations of the job on one MI355X (C ABI of include/ance_amd.h).  The only engine the
     product constructs; tests of the multi-process host logic inject a stand-in with this surface."""
 
-    def __init__(self, device=None, block_records=16384):
+    def __init__(self, device=None, block_records=None):
         import torch
         self.torch = torch
         self.device = torch.device(device if device is not None else "cuda")
@@ -198,7 +198,11 @@ class HipEngine:
         if n == 0:
             return out
         rb = cache.record_size
-        B = min(self.block_records, n)
+        # records per encode call: every call ends with the two internal streams of the encoder joining (half a micro-batch of
+        # idle lane on average) and with one partial micro-batch, so blocks are as large as a 64 MB pinned slot allows --
+        # 65,536 records at seq_len 128 (75 micro-batches per call), 32 k at 512, 8 k at 2,048
+        B = self.block_records or int(os.environ.get("ANCE_ENCODE_BLOCK", 0)) or max(4096, min(65536, (64 << 20) // rb))
+        B = min(B, n)
         ring = [torch.empty((B, rb), dtype=torch.uint8).pin_memory() for _ in range(3)]
         done = [None, None, None]
         for bi, b0 in enumerate(range(0, n, B)):

@@ -41,8 +41,10 @@ def _job(rank, world, data, ckpt, out, port, L=64, max_tokens=16384, precision=N
 
 
 @pytest.mark.parametrize("precision", [None, "fp16"])  # None: the job's default = the split (fp32-grade) mode
-def test_multi_rank_refresh_on_one_gpu(tmp_path, precision):
+def test_multi_rank_refresh_on_one_gpu(tmp_path, precision, monkeypatch):
     from safetensors.torch import save_file
+    monkeypatch.setenv("ANCE_ENCODE_BLOCK", "3000")  # several blocks per rank through the 3-deep pinned ring of encode_cache
+    monkeypatch.setenv("ANCE_SEARCH_CHUNK", "400")   # several exchange chunks per search (side-stream overlap of sharded_search)
     from oracle import encoder_ref, synth
     data = str(tmp_path / "data")
     synth.make_msmarco_like(data, n_passages=20000, n_train=1500, n_dev=301, L=64, Lq=32, seed=11, len_median=30)
