@@ -70,6 +70,8 @@ def main():
     ap.add_argument("--tokens-per-step", type=int, default=1 << 21)
     ap.add_argument("--search-only", action="store_true")
     ap.add_argument("--skip-search", action="store_true")
+    ap.add_argument("--precision", default=None, choices=["fp16", "split", "fp32"],
+                    help="encoder arithmetic (default: the library's default = split, fp32-grade)")
     a = ap.parse_args()
     import torch
     import bench
@@ -95,7 +97,7 @@ def main():
         n = max(256, int(a.tokens_per_step / mean_guess) // 64 * 64)
         lens = lens_fn(n).astype(np.int32)
         rec = torch.from_numpy(records(rng, lens, L, first, last, pad, lo, hi)).to(dev)
-        enc = Encoder(sd, arch, prefix, head, max_seq_len=min(L, 512), max_tokens=65536, device=dev)
+        enc = Encoder(sd, arch, prefix, head, max_seq_len=min(L, 512), max_tokens=65536, device=dev, precision=a.precision)
         out = torch.empty((n * chunks, 768), dtype=torch.float32, device=dev)
         enc.encode_records(rec, n_chunks=chunks, h_lens=lens, out=out)
         torch.cuda.synchronize()
@@ -111,7 +113,7 @@ def main():
             tl = np.concatenate([np.clip(lens.astype(np.float64) - 512 * c, 0, 512) for c in range(chunks)])
             tl = tl[tl > 0]
         flops = float((169869312.0 * tl + 36864.0 * tl * tl).sum())
-        print(json.dumps({"config": name, "items_per_sec": n / dt, "vectors_per_sec": n * chunks / dt,
+        print(json.dumps({"config": name, "encoder_precision": enc.precision, "items_per_sec": n / dt, "vectors_per_sec": n * chunks / dt,
                           "tokens_per_sec": float(lens.sum()) / dt, "mean_len": float(lens.mean()),
                           "algorithmic_tflops": flops / dt / 1e12, "items": n, "finite": bool(torch.isfinite(out).all())}))
         del enc, rec, out

@@ -20,7 +20,8 @@ for what in ${PMC_LEGS:-search encode_split}; do
   [ $what = encode_split ] && rx="gemm256_split_kernel|attention_split_kernel"
   echo "== kernel-trace $what"
   timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/pmc/kt_$what -o kt -- $cmd > gpurun_out/pmc/kt_$what.log 2>&1; echo "rc=$?"
-  if [ $what = encode_fp32 ]; then unset ANCE_ENCODER_STREAMS; continue; fi  # the audit path: kernel trace only
+  # the audit path and (PMC_TRACE_ONLY) the fp16 fast mode: kernel trace only
+  if [ $what = encode_fp32 ] || [[ " ${PMC_TRACE_ONLY:-} " == *" $what "* ]]; then unset ANCE_ENCODER_STREAMS; continue; fi
   echo "== pmc cycles $what (GRBM_GUI_ACTIVE = shader clocks of the dispatch: clock-independent cost, and the clock itself)"
   timeout 900 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES --kernel-trace --kernel-include-regex "$rx" --output-format csv -d gpurun_out/pmc/CYCLES_$what -o pmc -- $cmd > gpurun_out/pmc/CYCLES_$what.log 2>&1; echo "rc=$?"
   echo "== pmc L2 hit/miss $what"
