@@ -179,20 +179,23 @@ typedef struct AnceEncoder AnceEncoder;
 /* Bytes of the packed weight arena (fp16 GEMM operands + fp32 vectors) and of the activation
  * workspace for desc->max_tokens.  Both are caller-allocated device buffers, 256-byte aligned.
  *
- * Arithmetic.  Default: fp16 MFMA operands, fp32 accumulation, fp32 softmax / statistics / head; LayerNorm folded into the
- * GEMMs and the residual stream kept as fp16 (hi, lo) pairs (22 mantissa bits) -- max |delta| 3e-3 on unit-variance
- * embeddings against the reference's fp32 arithmetic (stated tolerance of the tests: 5e-3).
- * Input-distribution precondition of the default mode: a folded GEMM takes fp16(v) of the PRE-LayerNorm row v as its token
- * operand, so its rounding error scales with |v|, not |v - mean|.  A GEMM tile with a token whose |mean| rstd exceeds 2
- * therefore runs a second K loop over the lo halves on its own (22-bit operand, no host involvement); below that threshold the
- * error is at most sqrt(1 + 2^2) x the random-init figure.  Pre-LayerNorm values must stay below 65,504 (fp16 range).
- * Environment, read when a handle is created (the two size queries read ANCE_ENCODER_PRECISE / ANCE_ENCODER_SPLIT as well):
- *   ANCE_ENCODER_SPLIT=1     split mode: an fp32-GRADE result from the fp16 matrix cores -- every GEMM operand an fp16 pair
- *                            v = hi + lo, three MFMAs per k-step (hi hi + lo hi + hi lo) from four operand tiles staged once, fp32
- *                            softmax, exact erf GELU, fp32 head; max |delta| 2e-5 (stated).  What the Python layer selects by
- *                            default (precision="split"): the reference runs its encoder in fp32
+ * Arithmetic.  DEFAULT (nothing in the environment): the SPLIT mode -- an fp32-GRADE result from the fp16 matrix cores: every GEMM
+ * operand an fp16 pair v = hi + lo, three MFMAs per k-step (hi hi + lo hi + hi lo) from four operand tiles staged once, fp32
+ * accumulation, fp32 softmax, erf-GELU to fp32 grade, fp32 head; max |delta| 2e-5 (stated; 7e-6 measured at 12 layers) against the
+ * reference's fp32 arithmetic (model/models.py:149-157 runs in fp32).  Pre-LayerNorm values and GELU outputs must stay below
+ * 65,504 (the hi half is an fp16); weights may have any scale (stored times a per-matrix power of two).
+ * Environment, read when a handle is created (the two size queries read the mode switches as well):
+ *   ANCE_ENCODER_FP16=1      the fp16 FAST mode (ANCE_ENCODER_SPLIT=0 is another spelling): fp16 MFMA operands, fp32 accumulation, fp32
+ *                            softmax / statistics / head; LayerNorm folded into the GEMMs and the residual stream kept as fp16 (hi, lo)
+ *                            pairs (22 mantissa bits) -- max |delta| 3e-3 on unit-variance embeddings (stated tolerance of the tests:
+ *                            5e-3), 2.2 x the default's throughput.  A folded GEMM takes fp16(v) of the PRE-LayerNorm row v as its token
+ *                            operand, so its rounding error scales with |v|, not |v - mean|: a GEMM tile with a token whose |mean| rstd
+ *                            exceeds 2 runs a second K loop over the lo halves OF THOSE TOKENS (masked per row: a row's bits never
+ *                            depend on its tile mates); below that threshold the error is at most sqrt(1 + 2^2) x the random-init figure
+ *   ANCE_ENCODER_SPLIT=1     names the default explicitly; wins over ANCE_ENCODER_FP16
  *   ANCE_ENCODER_PRECISE=1   fp32 mode: fp32 operands on the fp32-input matrix cores, exact erf GELU, fp32 softmax -- the
- *                            reference's arithmetic (model/models.py:149-157); max |delta| 1e-5, ~9 x slower (the audit path)
+ *                            reference's arithmetic (model/models.py:149-157); max |delta| 1e-5, 4.4 x slower than the default (the audit
+ *                            path); wins over the other two switches
  *   ANCE_GEMM_NSPLIT=0       FFN1 without the N-split tile order (A/B switch)
  *   ANCE_ENCODER_STREAMS=n   internal streams / activation sets (1 or 2, default 2)
  *   ANCE_LN_FOLD=0 ANCE_HEAD_MFMA=0 ANCE_CLS_TAIL=0 ANCE_ATTN_COAL=0 ANCE_GEMM_DESC=0   A/B switches back to the previous
