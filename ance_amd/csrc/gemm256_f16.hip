@@ -299,6 +299,10 @@ __global__ void __launch_bounds__(G256_THREADS, 2) gemm256_split_kernel(const Ge
             P.S.voff[2 + h][j] = (uint32_t)(pipe_b_tile_row(h, r) * G.ldb + ch) * 2u;
         }
     const float winv = G.wscale_inv ? *G.wscale_inv : 1.0f;  // wave-uniform: a scalar load, long back when the epilogue starts
+#ifdef ANCE_MEASURE
+    unsigned long long *stamps_ = G.debug_mode == 64 ? g_gemm_stamps : nullptr;  // [block][8]: start, main loop done, statistics, end
+#endif
+    GSTAMP(0);
     epb_issue<EPI>(G, smem_f, m0, n0, w, l);
 #ifdef ANCE_SPLIT_V1
     const int NK = G.K / TK;
@@ -316,8 +320,14 @@ __global__ void __launch_bounds__(G256_THREADS, 2) gemm256_split_kernel(const Ge
 #else
     P.run(G.K / 32, acc);  // K-tile = 64 halves of a blocked pair row = 32 k of hi and lo
 #endif
+    GSTAMP(1);
     (void)epb_stats(G, smem_f, tid);
+    GSTAMP(2);
     gemm256_epilogue_split<EPI>(G, acc, smem_f, m0, n0, w, l, winv);
+#ifdef ANCE_MEASURE
+    if (stamps_) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    GSTAMP(3);
 }
 
 template <int EPI, bool ABLATE>
@@ -396,6 +406,7 @@ __global__ void __launch_bounds__(G256_THREADS, 2) gemm256_f16_kernel(const Gemm
 
 #ifdef ANCE_MEASURE
 unsigned long long *g_gemm_stamps_host = nullptr;
+int g_gemm_stamps_epi = EPI_RESLN;  // which epilogue's launches are stamped (ance_debug_gemm_stamps_epi)
 #endif
 
 template <bool ABLATE>
@@ -440,7 +451,7 @@ int launch256(int epi, const GemmArgs &G, hipStream_t st) {
     }
     const size_t lds = epi >= EPI_RESLN ? G256_LDS_BYTES + (size_t)EPB_FLOATS * sizeof(float) : G256_LDS_BYTES;
 #ifdef ANCE_MEASURE
-    if (epi == EPI_RESLN && g_gemm_stamps_host) {
+    if (epi == g_gemm_stamps_epi && g_gemm_stamps_host) {
         GemmArgs G2 = G;
         G2.debug_mode = 64;
         hipLaunchKernelGGL(k, dim3(blocks), dim3(G256_THREADS), lds, st, G2);
@@ -482,6 +493,9 @@ extern "C" void ance_debug_gemm_stamps(void *d_stamps) {
     unsigned long long *p = ance::g_gemm_stamps_host;
     (void)hipMemcpyToSymbol(HIP_SYMBOL(ance::g_gemm_stamps), &p, sizeof(p));
 }
+// measurement library only: the epilogue (gemm_f16.h: EPI_*) whose launches leave stamps; default EPI_RESLN.  The split kernels
+// (EPI_S_QKV 8, EPI_S_GELU 9, EPI_S_RESLN 10) fill slots 0..3: start, main loop done, statistics ready, stores drained
+extern "C" void ance_debug_gemm_stamps_epi(int epi) { ance::g_gemm_stamps_epi = epi; }
 // measurement library only (WRONG results): see g_res_ablate in gemm256_epilogue.h
 extern "C" void ance_debug_gemm_res_ablate(int bits) {
     (void)hipMemcpyToSymbol(HIP_SYMBOL(ance::g_res_ablate), &bits, sizeof(bits));

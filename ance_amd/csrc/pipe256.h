@@ -53,6 +53,17 @@ constexpr size_t PIPE_LDS_BYTES = (size_t)2 * PIPE_BUF_HALVES * sizeof(_Float16)
 #ifndef PIPE_PAIR3_STAGE_GAP
 #define PIPE_PAIR3_STAGE_GAP 2  // MFMA pairs between two LDS-DMA pieces of a PAIR3 phase (1: as the plain schedule)
 #endif
+#define PIPE_WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+// PAIR3 only: where the LDS-DMAs of a K-tile are issued.  0: all eight between the MFMAs of the two MFMA half-phases (as the plain
+// coarse schedule).  1: A-half1 of tile t+1 and A-half0 of tile t+2 (two pieces each) in the READ half-phases of P0 / P1 -- after the
+// phase's ds_reads, before its barrier, i.e. by the wave of the SIMD that is NOT in its MFMA half-phase, whose 24 MFMAs take 768
+// cycles while a read half-phase needs ~250 -- and only B-half0 / B-half1 of tile t+2 between the MFMAs of P1.  2: all eight in the
+// read half-phases.  The early forms wait for their own ds_reads BEFORE the barrier (s_waitcnt lgkmcnt(0)), so that a read has
+// completed in its read half-phase: the WAR distance of an early restage is then one full slot for both wave groups
+// (tests/test_pipe_schedule_model.py replays all three forms).
+#ifndef PIPE_PAIR3_EARLY
+#define PIPE_PAIR3_EARLY 0
+#endif
 
 // Row of the 256-row operand tile held at row r of half-tile h.
 __device__ __forceinline__ int pipe_a_tile_row(int h, int r) { return (((r >> 6) * 2 + h) << 6) + (r & 63); }
@@ -300,6 +311,41 @@ struct Pipe256T {
 
     template <int MODE>
     __device__ __forceinline__ void tile2(int t, f32x16 (&acc)[2][4]) {
+        if constexpr (PAIR3 && PIPE_PAIR3_EARLY > 0) {
+            // in flight when a tile starts (oldest first): A1(t), A0 B0 B1 (t+1) -- what the prologue leaves, too
+            // P0
+            read_a<0>(t);
+            read_b<0>(t);
+            read_b<1>(t);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (MODE <= 1) {
+                stage<1>(t + 1);
+                PIPE_WAIT_VM(8);  // retires A1(t); leaves A0 B0 B1 A1 of tile t+1
+            } else {
+                PIPE_WAIT_VM(0);
+            }
+            PIPE_WAIT_LGKM0();
+            mfma16<0, -1, -1, -1>(acc, t + 1);
+            // P1
+            read_a<1>(t);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (MODE == 0) {
+                stage<0>(t + 2);
+                if constexpr (PIPE_PAIR3_EARLY == 2) {
+                    stage<2>(t + 2);
+                    stage<3>(t + 2);
+                    PIPE_WAIT_VM(8);  // retires A0 B0 B1 of tile t+1; leaves A1(t+1) and A0 B0 B1 of tile t+2
+                } else {
+                    PIPE_WAIT_VM(4);  // retires A0 B0 B1 of tile t+1; leaves A1(t+1), A0(t+2)
+                }
+            } else if constexpr (MODE == 1) {
+                PIPE_WAIT_VM(2);      // retires A0 B0 B1 of tile t+1; leaves A1(t+1)
+            }
+            PIPE_WAIT_LGKM0();
+            if constexpr (MODE == 0 && PIPE_PAIR3_EARLY == 1) mfma16<1, 2, 3, -1>(acc, t + 2);
+            else mfma16<1, -1, -1, -1>(acc, t + 2);
+            return;
+        }
         // P0
         read_a<0>(t);
         read_b<0>(t);

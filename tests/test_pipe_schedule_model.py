@@ -44,13 +44,30 @@ def coarse(mode, t):
     ]
 
 
+def coarse_pair3_early(form):
+    """pipe256.h ``tile2<MODE>`` with PIPE_PAIR3_EARLY = form (1 or 2): phases carry a fourth entry, the half-tiles staged in the
+    READ half-phase (after the reads, before the wait), and these forms wait for their own ds_reads before the barrier."""
+    def phases(mode, t):
+        p0 = ([(A0, t), (B0, t), (B1, t)], 8 if mode <= 1 else 0, [], [(A1, t + 1)] if mode <= 1 else [])
+        if mode == 0:
+            if form == 2:
+                p1 = ([(A1, t)], 8, [], [(A0, t + 2), (B0, t + 2), (B1, t + 2)])
+            else:
+                p1 = ([(A1, t)], 4, [(B0, t + 2), (B1, t + 2)], [(A0, t + 2)])
+        else:
+            p1 = ([(A1, t)], 2 if mode == 1 else None, [], [])
+        return [p0, p1]
+    return phases
+
+
 def coarse_prologue():
     # stage tile 0 (A0 B0 B1 A1); vmcnt(2); barrier; stage A0 B0 B1 of tile 1
     return [[(A0, 0), (B0, 0), (B1, 0), (A1, 0)], 2, [(A0, 1), (B0, 1), (B1, 1)]]
 
 
-def replay(nk, phases_of, prologue):
-    """Replays a loop of ``nk`` K-tiles.  (The search filter's streamed loop over several corpus tiles is, from the
+def replay(nk, phases_of, prologue, reads_complete_before_barrier=False):
+    """Replays a loop of ``nk`` K-tiles.  reads_complete_before_barrier: the schedule waits ``lgkmcnt(0)`` before the barrier that
+    ends a read half-phase, so a read has completed in that slot (otherwise: in the MFMA half-phase that consumes it).  (The search filter's streamed loop over several corpus tiles is, from the
     schedule's point of view, one longer loop: K-tile indices simply continue into the next corpus tile.)"""
     total = nk
     phases = []
@@ -93,20 +110,28 @@ def replay(nk, phases_of, prologue):
         for g in (0, 1):
             # group g: R(p) in slot 2p + g, M(p) in slot 2p + 1 + g
             if (slot - g) % 2 == 0 and 0 <= (slot - g) // 2 < len(phases):
-                reads, w, _ = phases[(slot - g) // 2]
+                ph = phases[(slot - g) // 2]
+                reads, w = ph[0], ph[1]
+                early = ph[3] if len(ph) > 3 else []
                 for ht in reads:
                     # RAW: retired by both groups in an earlier slot
                     for gg in (0, 1):
                         assert ht in retired[gg], "read of %s in slot %d: group %d never waited for it" % (ht, slot, gg)
                         assert retired[gg][ht] < slot, "RAW: %s read in slot %d, group %d retired it in slot %d" % (
                             ht, slot, gg, retired[gg][ht])
+                for ht in early:  # LDS-DMAs issued in the read half-phase, behind the reads
+                    if ht[1] < total:
+                        stage(g, ht, slot)
                 if w is not None:
                     wait_pieces(g, w, slot)
+                if reads_complete_before_barrier:
+                    for ht in reads:
+                        read_done[g][ht] = slot
             if (slot - g) % 2 == 1 and 0 <= (slot - g - 1) // 2 < len(phases):
                 p = (slot - g - 1) // 2
-                reads, _, stages = phases[p]
+                reads, stages = phases[p][0], phases[p][2]
                 for ht in reads:
-                    read_done[g][ht] = slot  # consumed by this half-phase's MFMAs
+                    read_done[g].setdefault(ht, slot)  # consumed by this half-phase's MFMAs
                 for ht in stages:
                     if ht[1] < total:
                         stage(g, ht, slot)
@@ -126,6 +151,15 @@ def test_four_phase_schedule(nk, keep_b0):
 @pytest.mark.parametrize("nk", range(2, 14))
 def test_coarse_schedule(nk):
     replay(nk, coarse, coarse_prologue())
+
+
+@pytest.mark.parametrize("nk", range(2, 14))
+@pytest.mark.parametrize("form", [1, 2])
+def test_coarse_pair3_early_schedules(nk, form):
+    """The split GEMM's forms with LDS-DMAs issued in the read half-phases (PIPE_PAIR3_EARLY)."""
+    replay(nk, coarse_pair3_early(form), coarse_prologue(), reads_complete_before_barrier=True)
+    with pytest.raises(AssertionError):  # without the lgkmcnt(0) before the barrier the early restage races the other group's reads
+        replay(max(nk, 4), coarse_pair3_early(form), coarse_prologue(), reads_complete_before_barrier=False)
 
 
 def test_model_catches_a_broken_schedule():
