@@ -284,8 +284,6 @@ __global__ void __launch_bounds__(G256_THREADS, 2) gemm256_split_kernel(const Ge
 #ifdef ANCE_SPLIT_V1
     // round 4 (A/B builds): rows [hi (K) | lo' (K)], three K segments lo' x hi, hi x lo', hi x hi, one 2^-11 rescale in between
     Pipe256T<PipeSrcSplit, false, true, true> P;
-#elif defined(ANCE_SPLIT_ONEPHASE)
-    Pipe256One<PipeSrcDesc> P;  // one phase per K-tile (pipe256.h): measurement variant
 #else
     Pipe256T<PipeSrcDesc, false, true, true, true> P;
 #endif

@@ -420,130 +420,4 @@ struct Pipe256T {
     }
 };
 
-// ---- one phase per K-tile (the split GEMM's PAIR3 products; measurement variant, see gemm256_f16.hip: ANCE_SPLIT_ONEPHASE) ----------
-// The coarse schedule above spends ~150 cycles per slot (interval between two workgroup barriers) that are not MFMA issue -- the
-// hand-over of the matrix pipe from one wave group to the other -- whatever the slot holds: 16 MFMAs (fp16 GEMM: 76 % of the
-// issue rate), 24 (PAIR3: 84 %), with or without LDS-DMAs in it (PIPE_PAIR3_EARLY).  Here a K-tile is TWO slots instead of four:
-//   R(t)  24 ds_read_b128: every fragment of K-tile t (96 VGPRs)        M(t)  48 MFMAs
-// group g (wm) runs R(t) in slot 2t + g and M(t) in slot 2t + 1 + g, as before.  With two K-tile buffers tile t+1 replaces tile
-// t-1, whose last reads (group 1, slot 2t - 1, completed there: lgkmcnt(0) before the barrier) allow a restage from slot 2t on,
-// and group 0 reads it in slot 2t + 2: BOTH groups issue tile t+1 in slot 2t and retire it at the end of slot 2t + 1 --
-//   group 0: R(t) = reads, stage tile t+1, lgkmcnt(0) | M(t) = 48 MFMAs, vmcnt(0)
-//   group 1: R(t) = reads, vmcnt(0) (tile t+1), lgkmcnt(0) | M(t) = 48 MFMAs with the 8 pieces of tile t+2 between them
-// (group 1's M(t) is slot 2t + 2 = the issue slot of tile t+2).  Prologue: tile 0 by everybody, retired, barrier; group 1 stages
-// tile 1 before its extra barrier.  tests/test_pipe_schedule_model.py replays it (test_one_phase_schedule).
-template <class SRC>
-struct Pipe256One {
-    SRC S;
-    _Float16 *smem;
-    int w;
-    int ra[2], rb, kx[4];
-    f16x8 fa[4][4], fb[2][4];
-
-    __device__ __forceinline__ void init(_Float16 *smem_, int w_, int l) {
-        smem = smem_;
-        w = w_;
-        const int g = l >> 5, i = l & 31, wm = w >> 2, wn = w & 3;
-        const int c0 = g ^ ((i >> 1) & 7);
-#pragma unroll
-        for (int s = 0; s < 4; ++s) kx[s] = (c0 ^ (2 * s)) * 8;
-        ra[0] = (wm * 64 + i) * 64;
-        ra[1] = (wm * 64 + 32 + i) * 64;
-        rb = (wn * 32 + i) * 64;
-    }
-    template <int TYPE, int J>
-    __device__ __forceinline__ void stage_piece(int t) {
-        _Float16 *dst = smem + (t & 1) * PIPE_BUF_HALVES + TYPE * PIPE_HALF_HALVES + (w + 8 * J) * 512;
-        S.template issue<TYPE, J>(t, (pipe_lds_t *)dst);
-    }
-    __device__ __forceinline__ void stage_all(int t) {
-        stage_piece<0, 0>(t); stage_piece<0, 1>(t); stage_piece<2, 0>(t); stage_piece<2, 1>(t);
-        stage_piece<3, 0>(t); stage_piece<3, 1>(t); stage_piece<1, 0>(t); stage_piece<1, 1>(t);
-    }
-    __device__ __forceinline__ void read_all(int t) {
-        const _Float16 *base = smem + (t & 1) * PIPE_BUF_HALVES;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-#pragma unroll
-            for (int y = 0; y < 4; ++y) fa[y][s] = *reinterpret_cast<const f16x8 *>(base + (y >> 1) * PIPE_HALF_HALVES + ra[y & 1] + kx[s]);
-#pragma unroll
-            for (int x = 0; x < 2; ++x) fb[x][s] = *reinterpret_cast<const f16x8 *>(base + (2 + x) * PIPE_HALF_HALVES + rb + kx[s]);
-        }
-    }
-    __device__ __forceinline__ void bar() {
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    // 48 MFMAs: the three products of both k-steps for the wave's eight accumulators (an accumulator every eighth MFMA);
-    // STAGE: one LDS-DMA piece of K-tile ts after every sixth MFMA
-    template <bool STAGE>
-    __device__ __forceinline__ void mfma48(f32x16 (&acc)[2][4], int ts) {
-        constexpr int pa[6] = {0, 2, 0, 1, 3, 1}, pb[6] = {0, 0, 2, 1, 1, 3};
-#pragma unroll
-        for (int c = 0; c < 6; ++c) {
-#pragma unroll
-            for (int x = 0; x < 2; ++x) {
-#pragma unroll
-                for (int y = 0; y < 4; ++y)
-                    acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[x][pb[c]], fa[y][pa[c]], acc[x][y], 0, 0, 0);
-                if constexpr (STAGE) {
-                    __builtin_amdgcn_sched_barrier(0);
-                    constexpr int pc = 0;
-                    (void)pc;
-                    if (2 * c + x == 0) stage_piece<0, 0>(ts);
-                    if (2 * c + x == 1) stage_piece<0, 1>(ts);
-                    if (2 * c + x == 2) stage_piece<2, 0>(ts);
-                    if (2 * c + x == 3) stage_piece<2, 1>(ts);
-                    if (2 * c + x == 4) stage_piece<3, 0>(ts);
-                    if (2 * c + x == 5) stage_piece<3, 1>(ts);
-                    if (2 * c + x == 6) stage_piece<1, 0>(ts);
-                    if (2 * c + x == 7) stage_piece<1, 1>(ts);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-        }
-    }
-    // one K-tile of group 1 / group 0 (STAGE: there is a tile to stage -- t+2 for group 1, t+1 for group 0)
-    template <bool STAGE>
-    __device__ __forceinline__ void tile_g1(int t, f32x16 (&acc)[2][4]) {
-        read_all(t);
-        __builtin_amdgcn_sched_barrier(0);
-        PIPE_WAIT_VM(0);  // tile t+1 (issued during M(t-1) / the prologue)
-        PIPE_WAIT_LGKM0();
-        bar();
-        mfma48<STAGE>(acc, t + 2);
-        bar();
-    }
-    template <bool STAGE>
-    __device__ __forceinline__ void tile_g0(int t, f32x16 (&acc)[2][4]) {
-        read_all(t);
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr (STAGE) stage_all(t + 1);
-        PIPE_WAIT_LGKM0();
-        bar();
-        mfma48<false>(acc, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        PIPE_WAIT_VM(0);  // tile t+1
-        bar();
-    }
-    // Whole K loop of one output tile (NK >= 2).  On return every wave has passed the same number of barriers.
-    __device__ __forceinline__ void run(int NK, f32x16 (&acc)[2][4]) {
-        stage_all(0);
-        PIPE_WAIT_VM(0);
-        bar();
-        if (w >= 4) {  // group 1: one slot behind; tile 1 is "issued in slot 0"
-            stage_all(1);
-            bar();
-            for (int t = 0; t < NK - 2; ++t) tile_g1<true>(t, acc);
-            tile_g1<false>(NK - 2, acc);
-            tile_g1<false>(NK - 1, acc);
-        } else {
-            for (int t = 0; t < NK - 1; ++t) tile_g0<true>(t, acc);
-            tile_g0<false>(NK - 1, acc);
-            bar();  // leave: group 0 waits for group 1's last slot
-        }
-    }
-};
-
 }  // namespace ance

@@ -162,78 +162,6 @@ def test_coarse_pair3_early_schedules(nk, form):
         replay(max(nk, 4), coarse_pair3_early(form), coarse_prologue(), reads_complete_before_barrier=False)
 
 
-def replay_one_phase(nk, g1_issue_shift=0, g0_wait_late=False):
-    """pipe256.h ``Pipe256One``: one read half-phase R(t) (all 24 fragments of K-tile t) and one MFMA half-phase M(t) per K-tile;
-    group g runs R(t) in slot 2t + g and M(t) in slot 2t + 1 + g.  Whole K-tiles are staged (8 pieces per wave), vmcnt(0) waits.
-      group 0: R(t): reads(t), stage(t+1), [reads complete]      M(t): MFMAs, wait(0)
-      group 1: R(t): reads(t), wait(0),    [reads complete]      M(t): MFMAs + stage(t+2)
-    Asserts RAW (a tile is read only after both groups retired it in an earlier slot), WAR (a buffer is restaged only after both
-    groups' reads of its previous occupant completed in an earlier slot) and that nothing is left in flight.
-    g1_issue_shift / g0_wait_late: deliberately broken variants for the negative test."""
-    retired = {0: {}, 1: {}}
-    inflight = {0: [], 1: []}
-    read_done = {0: {}, 1: {}}
-
-    def stage(g, tile, slot):
-        if tile >= nk:
-            return
-        if tile >= 2:
-            for gg in (0, 1):
-                assert (tile - 2) in read_done[gg] and read_done[gg][tile - 2] < slot, \
-                    "WAR: tile %d restaged in slot %d, group %d finished reading tile %d in slot %s" % (
-                        tile, slot, gg, tile - 2, read_done[gg].get(tile - 2))
-        inflight[g].append(tile)
-
-    def wait0(g, slot):
-        for tile in inflight[g]:
-            retired[g][tile] = slot
-        inflight[g] = []
-
-    def read(g, tile, slot):
-        for gg in (0, 1):
-            assert tile in retired[gg] and retired[gg][tile] < slot, "RAW: tile %d read in slot %d, group %d retired it in slot %s" % (
-                tile, slot, gg, retired[gg].get(tile))
-
-    for g in (0, 1):           # prologue (slot -1): tile 0 by everybody, retired, barrier
-        stage(g, 0, -1)
-        wait0(g, -1)
-    stage(1, 1, 0)             # group 1 stages tile 1 before its extra barrier (= during slot 0)
-    for slot in range(2 * nk + 2):
-        for g in (0, 1):
-            if (slot - g) % 2 == 0 and 0 <= (slot - g) // 2 < nk:       # R(t)
-                tt = (slot - g) // 2
-                if g == 0 and g0_wait_late:
-                    wait0(0, slot)   # (broken form: the wait of M(t-1) moved behind the barrier)
-                read(g, tt, slot)
-                if g == 0:
-                    stage(0, tt + 1, slot)
-                else:
-                    wait0(1, slot)
-                read_done[g][tt] = slot                                  # lgkmcnt(0) before the barrier
-            if (slot - g) % 2 == 1 and 0 <= (slot - g - 1) // 2 < nk:   # M(t)
-                tt = (slot - g - 1) // 2
-                if g == 0:
-                    if not g0_wait_late:
-                        wait0(0, slot)
-                else:
-                    stage(1, tt + 2 + g1_issue_shift, slot)
-    for g in (0, 1):
-        assert not inflight[g]
-        assert sorted(read_done[g]) == list(range(nk))
-
-
-@pytest.mark.parametrize("nk", range(2, 14))
-def test_one_phase_schedule(nk):
-    replay_one_phase(nk)
-
-
-def test_one_phase_model_catches_broken_variants():
-    with pytest.raises(AssertionError):   # group 1 staging tile t+3 instead of t+2 during M(t): overwrites a buffer group 0 still has to read
-        replay_one_phase(8, g1_issue_shift=1)
-    with pytest.raises(AssertionError):   # group 0 waiting for tile t+1 only after the barrier that precedes its own read of it
-        replay_one_phase(8, g0_wait_late=True)
-
-
 def test_model_catches_a_broken_schedule():
     """The checker is not vacuous: restaging one phase earlier than allowed, or waiting for too little, fails."""
     def early_restage(mode, t):
