@@ -78,7 +78,7 @@ def generate_new_ann(args, output_num, checkpoint_path, preloaded_data, latest_s
     if model is None:
         from .encoder import load_model
         model = load_model("dpr", checkpoint_path, max_seq_length=args.max_seq_length,
-                           max_tokens=getattr(args, "max_tokens", 65536), device=getattr(args, "device", None),
+                           max_tokens=getattr(args, "max_tokens", 131072), device=getattr(args, "device", None),
                            precision=getattr(args, "encoder_precision", None))
 
     def enc(name, is_query):
@@ -187,7 +187,7 @@ def get_arguments(argv=None):
     p.add_argument("--passage_path", default=None, type=str, required=True)
     p.add_argument("--test_qa_path", default=None, type=str, required=True)
     p.add_argument("--trivia_test_qa_path", default=None, type=str, required=True)
-    p.add_argument("--max_tokens", default=65536, type=int)
+    p.add_argument("--max_tokens", default=131072, type=int)
     p.add_argument("--seed", default=None, type=int)
     p.add_argument("--encoder_precision", default="split", choices=["fp16", "split", "fp32"],
                    help="see ance_amd.ann_data_gen: split (default) is fp32-grade like the reference's forward, fp16 the fast mode")

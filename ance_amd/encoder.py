@@ -104,7 +104,7 @@ class Encoder:
     PRECISIONS = {"fp16": {"ANCE_ENCODER_FP16": "1"}, "split": {"ANCE_ENCODER_SPLIT": "1"}, "fp32": {"ANCE_ENCODER_PRECISE": "1"}}
 
     def __init__(self, state_dict, arch=ARCH_ROBERTA, prefix="roberta.", has_head=True, pad_token_id=None,
-                 ln_eps=None, max_seq_len=512, max_tokens=65536, device=None, precision=None):
+                 ln_eps=None, max_seq_len=512, max_tokens=131072, device=None, precision=None):
         """precision: None = whatever the environment says (include/ance_amd.h) -- with nothing set that is "split", the
         library's default: fp16-pair operands on the fp16 matrix cores, fp32-grade like the reference's own fp32 forward (2e-5;
         the mode in which the refresh reproduces the reference's negative ids).  "fp16" = the fast mode (fp16 MFMA operands,
@@ -302,7 +302,7 @@ def load_hf_state_dict(ckpt_dir):
     raise FileNotFoundError("no model.safetensors / pytorch_model.bin in %s" % ckpt_dir)
 
 
-def load_model(model_type, checkpoint_path, max_seq_length=128, max_tokens=65536, device=None, precision=None):
+def load_model(model_type, checkpoint_path, max_seq_length=128, max_tokens=131072, device=None, precision=None):
     """Registry of model/models.py:299-322 restricted to the encoders on the path.  precision: see ``Encoder``."""
     model_type = model_type.lower()
     if model_type in ("rdot_nll", "rdot_nll_multi_chunk"):

@@ -51,7 +51,7 @@ def parse():
     p.add_argument("--n-passages", type=int, default=N_PASSAGES, help="rows of the resident corpus (all ranks)")
     p.add_argument("--seq-len", type=int, default=128)
     p.add_argument("--topk", type=int, default=200)
-    p.add_argument("--max-tokens", type=int, default=65536)
+    p.add_argument("--max-tokens", type=int, default=131072, help="tokens per encoder micro-batch (the job's --max_tokens default)")
     p.add_argument("--layers", type=int, default=12)
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="time budget per CPU-baseline leg")

@@ -9,7 +9,7 @@ from ance_amd.encoder import ARCH_ROBERTA, Encoder  # noqa: E402
 mode = sys.argv[1] if len(sys.argv) > 1 else "split"
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 block = int(sys.argv[3]) if len(sys.argv) > 3 else 16384
-max_tokens = int(sys.argv[4]) if len(sys.argv) > 4 else 65536
+max_tokens = int(sys.argv[4]) if len(sys.argv) > 4 else 131072
 sd = bench.random_init_roberta_base(torch, 12, seed=0)
 enc = Encoder(sd, ARCH_ROBERTA, "roberta.", True, max_seq_len=128, max_tokens=max_tokens, precision=mode)
 rec, lens = bench.synthetic_records(np.random.default_rng(1234), block, 128)

@@ -522,3 +522,26 @@ def test_re_encoding_into_a_searched_buffer_rebuilds_the_search_image():
         assert torch.equal(I, If) and torch.equal(D, Df), "round %d: stale search image" % round_
         results.append(I.clone())
     assert not torch.equal(results[0], results[1])
+
+
+def test_large_micro_batches_change_no_row():
+    """The job's default micro-batch is 131,072 tokens (ance_amd.ann_data_gen --max_tokens): 160 k tokens through two such
+    micro-batches give bit for bit the rows that ten 16,384-token micro-batches give, in the default (split) arithmetic and in the
+    fp16 fast mode -- operand matrices of 1.6 GB per GEMM stay below the 4 GiB of a buffer descriptor, token offsets below 2^31."""
+    from ance_amd.encoder import ARCH_ROBERTA, Encoder
+    from oracle import encoder_ref, synth
+    sd = encoder_ref.random_state_dict(seed=50, n_layers=2, ln_jitter=0.1)
+    rng = np.random.default_rng(51)
+    n = 2200
+    lens = synth.lognormal_lengths(rng, n, 70, 0.45, 8, 128).astype(np.int32)
+    ids = synth.make_records(rng, n, 128, lens.astype(np.int64))
+    assert 140_000 < int(lens.sum()) < 2 * 131072
+    ids_d, lens_d = torch.from_numpy(ids).cuda(), torch.from_numpy(lens).cuda()
+    for mode in ("split", "fp16"):
+        big = Encoder(sd, ARCH_ROBERTA, "roberta.", True, max_seq_len=128, max_tokens=131072, precision=mode)
+        a = big.encode_ids(ids_d, lens_d, h_lens=lens)
+        del big
+        small = Encoder(sd, ARCH_ROBERTA, "roberta.", True, max_seq_len=128, max_tokens=16384, precision=mode)
+        b = small.encode_ids(ids_d, lens_d, h_lens=lens)
+        del small
+        assert torch.isfinite(a).all() and torch.equal(a, b), mode
