@@ -278,6 +278,8 @@ struct Pipe256T {
         for (int step = 0; step < 2 * PER; ++step) {
             // P0 runs B-half0 first (it was read first); P1 runs B-half1 first (either order is fine for the result:
             // the two halves accumulate into different registers)
+            // (PAIR3 with the two B halves alternating -- an accumulator every fourth MFMA instead of every second -- measures the
+            // same: profiles/r05_ab_pair3_mfma_order.jsonl)
             const int xx = (step / PER) ^ YH, c = step % PER;
             const int sa = PAIR3 ? pa[c] : c, sb = PAIR3 ? pb[c] : c;
 #pragma unroll
