@@ -399,7 +399,7 @@ __device__ __forceinline__ void gemm256_epilogue(const GemmArgs &G, f32x16 (&acc
 //     Phi(x) = x >= 0 ? 1 - e : e,    e = erfc(|x| / sqrt 2) / 2 = 2^q(z),  z = min(|x| / sqrt 2, 6.6)
 // with q a degree-9 polynomial fit of log2(erfc(z) / 2) on [0, 6.6] (weighted for the ABSOLUTE error of e: approximation error
 // 1.1e-9; monomial in z, so that near z = 0 the sum is -1 plus small terms; beyond z = 6.6 e < 2^-66): 9 fma + v_exp_f32 + 6.
-// Measured against the exact value in fp32 emulation (tests/test_gelu_poly.py, 12 M points): |error| / |x| <= 1.1e-7 everywhere
+// Measured against the exact value in fp32 emulation (tests/test_gelu_poly.py, 8 M points): |error| / |x| <= 1.1e-7 everywhere
 // -- torch's own fp32 erf-GELU, which is what the reference runs, is at 3.7e-7 -- mean |error| 1.7e-8 (torch 4.5e-8).
 // (contraction off here and in the split epilogue: hipcc contracts a * b + c into an fma in SOME of the unrolled instances of
 // a loop and not in others, so a row's last bit would depend on which pass / register slot of the tile it lands in -- and with
