@@ -248,3 +248,43 @@ def test_maxp_refresh_job_end_to_end(golden_dir, tmp_path):
         assert not unexplained, unexplained
         assert same_sets >= 0.85 * len(ref_lines), (same_sets, len(ref_lines))
         assert d_ndcg <= 0.07, d_ndcg  # 8 dev queries: one near-tie swap at rank <= 10 moves NDCG@10 by up to 0.06
+
+
+def test_cli_with_the_references_flags_and_nothing_else(tmp_path):
+    """`python -m ance_amd.ann_data_gen <the reference launcher's flags>` as a process: no precision flag,
+    no environment -- the job must run the fp32-grade split arithmetic and write the files an in-process run of the default
+    arithmetic writes, byte for byte (the reference's contract: drivers/run_ann_data_gen.py:443-627 flags, :314-334 files)."""
+    import subprocess
+    import sys
+    from safetensors.torch import save_file
+    from ance_amd import ann_data_gen as adg
+    from ance_amd import negatives
+    from oracle import encoder_ref, synth
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    data = str(tmp_path / "data")
+    synth.make_msmarco_like(data, n_passages=6000, n_train=300, n_dev=50, L=64, Lq=32, seed=21, len_median=30)
+    sd = encoder_ref.random_state_dict(seed=9, n_layers=2, ln_jitter=0.1)
+    ckpt = tmp_path / "train" / "checkpoint-700"
+    ckpt.mkdir(parents=True)
+    save_file({k: v.contiguous() for k, v in sd.items()}, str(ckpt / "model.safetensors"))
+    (ckpt / "scheduler.pt").write_text("commit marker")
+    out = str(tmp_path / "out_cli")
+    env = {k: v for k, v in os.environ.items() if not k.startswith("ANCE_ENCODER_") and k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    cmd = [sys.executable, "-m", "ance_amd.ann_data_gen", "--training_dir", str(tmp_path / "train"), "--init_model_dir", "/nonexistent",
+           "--model_type", "rdot_nll", "--output_dir", out, "--cache_dir", out, "--data_dir", data, "--max_seq_length", "64",
+           "--max_query_length", "32", "--per_gpu_eval_batch_size", "16", "--topk_training", "100", "--negative_sample", "8",
+           "--end_output_num", "0", "--ann_chunk_factor", "1", "--seed", "4321"]
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    no, train_path, nd = adg.get_latest_ann_data(out)
+    assert no == 0 and adg.get_checkpoint_no(nd["checkpoint"]) == 700
+    # the same job in process, arithmetic spelled out
+    out2 = str(tmp_path / "out_split")
+    args = types.SimpleNamespace(data_dir=data, output_dir=out2, cache_dir=out2, inference=False, topk_training=100, negative_sample=8,
+                                 ann_chunk_factor=1, ann_measure_topk_mrr=False, model_type="rdot_nll", max_seq_length=64,
+                                 max_query_length=32, device=torch.device("cuda"), encoder_precision="split")
+    train_pos, dev_pos = negatives.load_positive_ids(data)
+    random.seed(4321)
+    adg.generate_new_ann(args, 0, nd["checkpoint"], train_pos, dev_pos, 700)
+    for name in ("ann_training_data_0", "ann_ndcg_0"):
+        assert open(os.path.join(out, name)).read() == open(os.path.join(out2, name)).read(), name
