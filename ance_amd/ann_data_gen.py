@@ -101,8 +101,13 @@ class Dist:
     comm = None
 
     def _timed(self, name, t, fn):
-        if self.comm is None or not t.is_cuda:
+        if self.comm is None:
             return fn()
+        if not t.is_cuda:  # host-staged collective (gloo): wall clock of the blocking call
+            t0 = time.perf_counter()
+            r = fn()
+            self.comm.setdefault(name, []).append((None, 1e3 * (time.perf_counter() - t0), t.numel() * t.element_size()))
+            return r
         import torch
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -118,7 +123,7 @@ class Dist:
         if not self.comm:
             return {}
         torch.cuda.synchronize()
-        return {k: {"ms": sum(a.elapsed_time(b) for a, b, _ in v), "calls": len(v), "bytes": sum(n for _, _, n in v)}
+        return {k: {"ms": sum(b if a is None else a.elapsed_time(b) for a, b, _ in v), "calls": len(v), "bytes": sum(n for _, _, n in v)}
                 for k, v in self.comm.items()}
 
     def all_gather_rows(self, t, per):
