@@ -336,6 +336,8 @@ def sharded_search(engine, dist, x_local, row_base, q_all, k):
         main.wait_stream(side)
     if dist.rank != 0:
         return None, None
+    if not out_D:  # no queries at all
+        return (torch.empty((0, k), dtype=torch.float32, device=dev), torch.empty((0, k), dtype=torch.int64, device=dev))
     D_all, I_all = torch.cat(out_D, dim=0), torch.cat(out_I, dim=0)
     if side is not None:  # allocated under the side stream, used from here on by the caller's
         D_all.record_stream(main)
