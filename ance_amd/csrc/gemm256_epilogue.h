@@ -420,6 +420,24 @@ __device__ __forceinline__ float gelu_exact(float x) {
     return x * (x >= 0.0f ? 1.0f - e : e);
 }
 
+// Output stores of the split epilogues are NON-TEMPORAL: the outputs of a launch (0.6-1.6 GB) are consumed by the next kernel and
+// only pass through the 4 MB L2s on their way out, where they evict the operand panels the main loops re-read.  Same-box A/B
+// (profiles/r05_ab_nt_store.jsonl, three alternations): FFN1 -0.7 %, the attention that follows the QKV GEMM -2.5 %, step +0.3 %.
+// (ANCE_EPI_PLAIN_STORE: A/B builds with ordinary stores.)
+#ifndef ANCE_EPI_PLAIN_STORE
+__device__ __forceinline__ void epi_pair_store_nt(const f32x4 v, _Float16 *row, int W, int n) {
+    f16x4 h, r;
+    pair_split4(v, &h, &r);
+    __builtin_nontemporal_store(h, reinterpret_cast<f16x4 *>(row + pair_hi_col(n, W)));
+    __builtin_nontemporal_store(r, reinterpret_cast<f16x4 *>(row + pair_lo_col(n, W)));
+}
+#define EPI_PAIR_STORE(v, row, W, n) epi_pair_store_nt(v, row, W, n)
+#define EPI_F32_STORE(p, v) __builtin_nontemporal_store(v, p)
+#else
+#define EPI_PAIR_STORE(v, row, W, n) pair_store4(v, row, W, n)
+#define EPI_F32_STORE(p, v) (*(p) = (v))
+#endif
+
 // One structure for the three of them: 4 passes over the wave's 128 rows, each through the wave-private fp32 slab
 // [32 m][64 n] (as EPI_RES32 / EPI_RESLN), so that on read-back a lane owns 4 consecutive columns of a row and global
 // traffic is whole 16-byte (fp32) or 8-byte (fp16) row segments.
@@ -483,18 +501,18 @@ __device__ __forceinline__ void gemm256_epilogue_split(const GemmArgs &G, f32x16
                     const float res = (float)rh[it][e] + (float)rl[it][e] * PAIR_LO_INV;  // exact in fp32: 22 bits
                     v[e] = __builtin_fmaf(v[e], winv, __builtin_fmaf(res - mean[it], a, v0[e] + v2[e]));
                 }
-                pair_store4(v, G.out16 + row * G.ldc, G.N, nw0 + c4 * 4);
+                EPI_PAIR_STORE(v, G.out16 + row * G.ldc, G.N, nw0 + c4 * 4);
                 vv[it] = v;
             } else {
                 const float mr = mean[it] * rstd[it], rw = rstd[it] * winv;  // r (acc winv) = acc (r winv): winv is a power of two
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(v[e], rw, __builtin_fmaf(-mr, v1[e], v0[e]));
                 if constexpr (EPI == EPI_S_QKV) {
-                    *reinterpret_cast<f32x4 *>(G.out32 + row * G.ldc + nw0 + c4 * 4) = v;
+                    EPI_F32_STORE(reinterpret_cast<f32x4 *>(G.out32 + row * G.ldc + nw0 + c4 * 4), v);
                 } else {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = gelu_exact(v[e]);
-                    pair_store4(v, G.out16 + row * G.ldc, G.N, nw0 + c4 * 4);
+                    EPI_PAIR_STORE(v, G.out16 + row * G.ldc, G.N, nw0 + c4 * 4);
                 }
             }
         }
