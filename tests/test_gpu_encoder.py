@@ -545,3 +545,38 @@ def test_large_micro_batches_change_no_row():
         b = small.encode_ids(ids_d, lens_d, h_lens=lens)
         del small
         assert torch.isfinite(a).all() and torch.equal(a, b), mode
+
+
+def test_split_mode_with_weights_of_very_different_scales():
+    """The split GEMM stores every weight matrix times its own power of two (largest element in [2^13, 2^14): csrc/encoder.hip:
+    weight_pair_scale) and undoes it in the epilogue.  Random-init weights are all ~0.02, so every other test exercises ONE
+    exponent; here the matrices of a 3-layer model are rescaled by factors between 2^-7 and 2^9 (Q / K / V by different ones: they
+    share a scale slot; one matrix gets a single huge outlier), and the result must stay fp32-grade: within 4 x the distance of the
+    fp32 oracle from the fp64 oracle (+ the stated 2e-5)."""
+    from oracle import encoder_ref, synth
+    n_layers = 3
+    sd = dict(encoder_ref.random_state_dict(seed=61, n_layers=n_layers, ln_jitter=0.1))
+    factors = {"attention.self.query": 6.0, "attention.self.key": 1.0 / 6.0, "attention.self.value": 37.0, "attention.output.dense": 1.0 / 40.0,
+               "intermediate.dense": 300.0, "output.dense": 1.0 / 120.0}
+    for i in range(n_layers):
+        for name, f in factors.items():
+            k = "roberta.encoder.layer.%d.%s.weight" % (i, name)
+            sd[k] = sd[k] * (f if i != 1 else 1.0 / f)       # the middle layer the other way round
+    w = sd["roberta.encoder.layer.2.output.dense.weight"].clone()
+    w[5, 77] = 9.0                                            # one outlier 50,000 x the typical element of that matrix
+    sd["roberta.encoder.layer.2.output.dense.weight"] = w
+    rng = np.random.default_rng(62)
+    lens = np.array([1, 2, 31, 33, 64, 65, 96, 128, 70, 9, 100, 50], dtype=np.int32)
+    ids = synth.make_records(rng, len(lens), 128, lens.astype(np.int64))
+    with torch.no_grad():
+        sd64 = {k: v.double() for k, v in sd.items()}
+        want64 = encoder_ref.rdot_nll_ln_emb(sd64, torch.from_numpy(ids), encoder_ref.mask_from_lengths(lens, 128), n_layers=n_layers).numpy()
+        want32 = encoder_ref.rdot_nll_ln_emb(sd, torch.from_numpy(ids), encoder_ref.mask_from_lengths(lens, 128), n_layers=n_layers).numpy()
+    from ance_amd.encoder import ARCH_ROBERTA, Encoder
+    enc = Encoder(sd, ARCH_ROBERTA, "roberta.", True, max_seq_len=128, max_tokens=2048, precision="split")
+    got = enc.encode_ids(torch.from_numpy(ids).cuda(), torch.from_numpy(lens).cuda(), h_lens=lens).cpu().numpy()
+    e32 = float(np.abs(want32.astype(np.float64) - want64).max())
+    e = float(np.abs(got.astype(np.float64) - want64).max())
+    with open(os.path.join(OUT, "encoder_parity.jsonl"), "a") as f:
+        f.write(json.dumps(dict(case="split_mode_weight_scales", max_abs_vs_fp64=e, fp32_oracle_vs_fp64=e32)) + "\n")
+    assert np.isfinite(got).all() and e <= 4.0 * e32 + 2e-5, (e, e32)
