@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("ANCE_AMD_LIB") or os.path.join(_HERE, "libance_amd.so
 CSRC = os.path.join(_HERE, "csrc")
 
 ANCE_OK = 0
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 c_i32p = ctypes.POINTER(ctypes.c_int32)
 c_i64p = ctypes.POINTER(ctypes.c_int64)
@@ -26,7 +26,13 @@ class AnceEncoderDesc(ctypes.Structure):
         ("n_heads", ctypes.c_int32), ("intermediate", ctypes.c_int32), ("vocab_size", ctypes.c_int32),
         ("max_position", ctypes.c_int32), ("pad_token_id", ctypes.c_int32), ("ln_eps", ctypes.c_float),
         ("has_head", ctypes.c_int32), ("max_seq_len", ctypes.c_int32), ("max_tokens", ctypes.c_int32),
+        ("precision", ctypes.c_int32),
     ]
+
+
+# AnceEncoderDesc.precision (include/ance_amd.h: ANCE_PRECISION_*)
+PRECISION_CODES = {None: 0, "split": 1, "fp16": 2, "fp32": 3}
+PRECISION_NAMES = {1: "split", 2: "fp16", 3: "fp32"}
 
 
 # name -> (restype, argtypes): every symbol include/ance_amd.h declares
@@ -40,6 +46,10 @@ SYMBOLS = {
     "ance_ip_topk": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64,
                                     ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                     ctypes.c_size_t, ctypes.c_void_p]),
+    "ance_ip_topk_scan_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int64, ctypes.c_int64, ctypes.c_int, ctypes.c_int]),
+    "ance_ip_topk_scan": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64,
+                                         ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                         ctypes.c_size_t, ctypes.c_void_p]),
     "ance_ip_index_bytes": (ctypes.c_size_t, [ctypes.c_int64, ctypes.c_int]),
     "ance_ip_index_build": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t,
                                            ctypes.c_void_p]),
@@ -59,6 +69,8 @@ SYMBOLS = {
                                            ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p,
                                            ctypes.c_size_t, ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p)]),
     "ance_encoder_destroy": (None, [ctypes.c_void_p]),
+    "ance_encoder_precision": (ctypes.c_int, [ctypes.c_void_p]),
+    "ance_encoder_range_faults": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
     "ance_encode_records": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
                                            ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),
     "ance_encode_ids": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
@@ -94,6 +106,10 @@ _lib = None
 
 class AnceLibraryError(RuntimeError):
     pass
+
+
+class AnceRangeError(AnceLibraryError):
+    """The split (default) arithmetic met a value outside the fp16 range -- its stated precondition -- or produced NaN rows."""
 
 
 def build(verbose=False, force=False):

@@ -88,13 +88,16 @@ class Dist:
         if self.on:
             self.dist.barrier()
 
-    def all_gather_scalars(self, v):
-        """Every rank's integer ``v`` in rank order (host-side object collective: tiny, once per search)."""
+    def all_gather_scalars(self, v, device=None):
+        """Every rank's integer ``v`` in rank order: one all-gather of an int64 (no pickling, no object collective)."""
+        import torch
         if not self.on or self.world == 1:
             return [int(v)]
-        box = [None] * self.world
-        self.dist.all_gather_object(box, int(v))
-        return [int(b) for b in box]
+        dev = torch.device("cpu") if (device is None or self.dist.get_backend() == "gloo") else device
+        mine = torch.tensor([int(v)], dtype=torch.int64, device=dev)
+        parts = [torch.empty_like(mine) for _ in range(self.world)]
+        self.dist.all_gather(parts, mine)
+        return [int(t.item()) for t in parts]
 
     # ``comm``: None, or a dict the caller installed -- every device collective is then bracketed by events on the stream it
     # is issued on and ``comm_ms()`` adds them up per collective (bench.py --gpus N prints it)
@@ -224,6 +227,9 @@ class HipEngine:
             ev.record()
             done[slot] = ev
             enc.encode_records(dev, n_chunks=chunks, h_lens=lens, out=out[b0 * chunks:b1 * chunks])
+        # range guard of the split arithmetic: blocks whose counters have arrived were checked as the loop went; the rest here
+        # (one synchronisation per collection -- the caller is about to search or gather these rows anyway)
+        enc.check_range(sync=True)
         return out
 
     def search(self, x, row_base, q, k):
@@ -261,6 +267,7 @@ class HipEngine:
         return self.torch.from_numpy(np.ascontiguousarray(a)).to(self.device)
 
 
+DRIVER_MAX_TOKENS = 131072  # the refresh drivers' micro-batch (the library default is 65,536: ance_amd.encoder.Encoder)
 SEARCH_CHUNK = 32768  # queries per exchange step = the search kernels' launch chunk (csrc/ip_topk_fast.hip)
 
 
@@ -275,7 +282,7 @@ def _unpack_lists(buf):
     return buf[..., 0].contiguous().view(torch.float32), buf[..., 1]
 
 
-def sharded_search(engine, dist, x_local, row_base, q_all, k):
+def sharded_search(engine, dist, x_local, row_base, q_all, k, row_bases=None):
     """Exact top-k of ``q_all`` over the union of every rank's shard.  Every rank scans its shard for ALL queries; the
     per-shard lists are then exchanged by QUERY OWNER -- rank j receives every rank's lists for its block of the queries with one
     all-to-all and merges them under the canonical order (the reference's own shard-search-then-merge:
@@ -285,7 +292,8 @@ def sharded_search(engine, dist, x_local, row_base, q_all, k):
     The exchange runs per launch chunk of ``SEARCH_CHUNK`` queries on a side stream: chunk i's all-to-all + merge + gather
     overlap chunk i + 1's scan (with RCCL the collective synchronises with the stream it is issued on; gloo's host-staged
     collectives are simply synchronous).  On the wire a list entry is (score fp32, LOCAL row id int32): the receiver adds the
-    sender's ``row_base`` (exchanged once), so ids travel in 4 bytes whatever the corpus size.
+    sender's ``row_base``, so ids travel in 4 bytes whatever the corpus size.  ``row_bases``: every rank's row_base in rank order
+    when the caller knows them (the refresh does: ``cache.shard_range`` is a pure function of the rank); else one int64 all-gather.
     Returns (D, I) on rank 0 and (None, None) elsewhere (only rank 0 post-processes)."""
     if dist.world == 1:
         return engine.search(x_local, row_base, q_all, k)
@@ -293,7 +301,9 @@ def sharded_search(engine, dist, x_local, row_base, q_all, k):
     W, nq = dist.world, q_all.shape[0]
     dev = q_all.device
     on_gpu = q_all.is_cuda
-    bases = dist.all_gather_scalars(int(row_base))  # row_base of every rank, in rank order
+    bases = [int(b) for b in row_bases] if row_bases is not None else dist.all_gather_scalars(int(row_base), dev)
+    if len(bases) != W or bases[dist.rank] != int(row_base):
+        raise ValueError("sharded_search: row_bases %r do not match this rank's row_base %d" % (bases, int(row_base)))
     base_t = torch.tensor(bases, dtype=torch.int64, device=dev).view(W, 1, 1)
     main = torch.cuda.current_stream(dev) if on_gpu else None
     side = engine.side_stream() if on_gpu and hasattr(engine, "side_stream") else None
@@ -319,6 +329,11 @@ def sharded_search(engine, dist, x_local, row_base, q_all, k):
             Dm, Im = engine.merge(Dp, Ip)                                           # [per, k], global ids
             Dg, Ig = dist.gather_rows_to_root(Dm), dist.gather_rows_to_root(Im)
             if dist.rank == 0:
+                if side is not None:
+                    # allocated and written under the side stream, concatenated below on the caller's: the caching allocator
+                    # must not hand these blocks to a side-stream allocation of a later chunk before that read has run
+                    Dg.record_stream(main)
+                    Ig.record_stream(main)
                 out_D.append(Dg[:n])
                 out_I.append(Ig[:n])
 
@@ -338,11 +353,13 @@ def sharded_search(engine, dist, x_local, row_base, q_all, k):
         return None, None
     if not out_D:  # no queries at all
         return (torch.empty((0, k), dtype=torch.float32, device=dev), torch.empty((0, k), dtype=torch.int64, device=dev))
-    D_all, I_all = torch.cat(out_D, dim=0), torch.cat(out_I, dim=0)
-    if side is not None:  # allocated under the side stream, used from here on by the caller's
-        D_all.record_stream(main)
-        I_all.record_stream(main)
-    return D_all, I_all
+    # (main has waited for the side stream above: the concatenation runs, and allocates, on the caller's stream)
+    return torch.cat(out_D, dim=0), torch.cat(out_I, dim=0)
+
+
+def shard_row_bases(n_records, world, chunks=1):
+    """row_base of every rank's shard, in rank order: ``encode_collection`` shards by ``cache.shard_range``, a pure function."""
+    return [shard_range(n_records, r, world)[0] * chunks for r in range(world)]
 
 
 def encode_collection(engine, dist, model, cache, is_query, chunks=1, r_begin=0, r_end=None):
@@ -408,7 +425,7 @@ def generate_new_ann(args, output_num, checkpoint_path, training_query_positive_
     if model is None:
         from .encoder import load_model
         model = load_model(args.model_type, checkpoint_path, max_seq_length=args.max_seq_length,
-                           max_tokens=getattr(args, "max_tokens", 131072), device=getattr(args, "device", None),
+                           max_tokens=getattr(args, "max_tokens", None) or DRIVER_MAX_TOKENS, device=getattr(args, "device", None),
                            precision=getattr(args, "encoder_precision", None))
     chunks = getattr(model, "chunks", 1)
     ph.mark("load_model")
@@ -442,9 +459,10 @@ def generate_new_ann(args, output_num, checkpoint_path, training_query_positive_
     q_all = gather_queries(dist, q_local, n_q)
     ph.mark("gather_queries")
 
-    _, dev_I = sharded_search(engine, dist, p_local, p_row0, dev_all, 100)
+    bases = shard_row_bases(n_rows // chunks, dist.world, chunks)
+    _, dev_I = sharded_search(engine, dist, p_local, p_row0, dev_all, 100, row_bases=bases)
     ph.mark("search_dev")
-    _, I = sharded_search(engine, dist, p_local, p_row0, q_all, args.topk_training)
+    _, I = sharded_search(engine, dist, p_local, p_row0, q_all, args.topk_training, row_bases=bases)
     logger.info("***** Done ANN Index *****")
     ph.mark("search_train")
 
@@ -555,12 +573,12 @@ def get_arguments(argv=None):
     p.add_argument("--config_name", default="", type=str)
     p.add_argument("--tokenizer_name", default="", type=str)
     # additions (not in the reference)
-    p.add_argument("--max_tokens", default=131072, type=int,
+    p.add_argument("--max_tokens", default=DRIVER_MAX_TOKENS, type=int,
                    help="tokens per encoder micro-batch (131,072: half as many launch ramps and partial last GEMM rounds as 65,536, +1.3 %; "
                         "the activation workspace scales with it: 11 GB for the two lanes of the default arithmetic)")
     p.add_argument("--seed", default=None, type=int, help="seed `random` before negative sampling")
-    p.add_argument("--encoder_precision", default="split", choices=["fp16", "split", "fp32"],
-                   help="encoder arithmetic: split (default) = fp16-pair operands on the fp16 matrix cores, fp32-grade like the reference's "
+    p.add_argument("--encoder_precision", default=None, choices=["fp16", "split", "fp32"],
+                   help="encoder arithmetic (overrides the ANCE_ENCODER_* environment switches; with neither, split): split = fp16-pair operands on the fp16 matrix cores, fp32-grade like the reference's "
                         "own fp32 forward (2e-5 on the embeddings; reproduces the reference's negative ids up to proven near-ties); fp16 = "
                         "fp16 MFMA operands, the fast mode (3e-3, ~2.2 x the throughput, about half of the negative lists identical); "
                         "fp32 = fp32 operands (audit path)")

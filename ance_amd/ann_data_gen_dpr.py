@@ -78,7 +78,7 @@ def generate_new_ann(args, output_num, checkpoint_path, preloaded_data, latest_s
     if model is None:
         from .encoder import load_model
         model = load_model("dpr", checkpoint_path, max_seq_length=args.max_seq_length,
-                           max_tokens=getattr(args, "max_tokens", 131072), device=getattr(args, "device", None),
+                           max_tokens=getattr(args, "max_tokens", None) or adg.DRIVER_MAX_TOKENS, device=getattr(args, "device", None),
                            precision=getattr(args, "encoder_precision", None))
 
     def enc(name, is_query):
@@ -98,9 +98,10 @@ def generate_new_ann(args, output_num, checkpoint_path, preloaded_data, latest_s
     q_all = adg.gather_queries(dist, q_local, n_q)
     dq_all = adg.gather_queries(dist, dq_local, n_dq)
     tq_all = adg.gather_queries(dist, tq_local, n_tq)
-    _, dev_I = adg.sharded_search(engine, dist, p_local, p_row0, dq_all, 100)
-    _, triv_I = adg.sharded_search(engine, dist, p_local, p_row0, tq_all, 100)
-    _, I = adg.sharded_search(engine, dist, p_local, p_row0, q_all, args.topk_training)
+    bases = adg.shard_row_bases(n_rows, dist.world)
+    _, dev_I = adg.sharded_search(engine, dist, p_local, p_row0, dq_all, 100, row_bases=bases)
+    _, triv_I = adg.sharded_search(engine, dist, p_local, p_row0, tq_all, 100, row_bases=bases)
+    _, I = adg.sharded_search(engine, dist, p_local, p_row0, q_all, args.topk_training, row_bases=bases)
     logger.info("***** Done ANN Index *****")
 
     result = None
@@ -187,9 +188,9 @@ def get_arguments(argv=None):
     p.add_argument("--passage_path", default=None, type=str, required=True)
     p.add_argument("--test_qa_path", default=None, type=str, required=True)
     p.add_argument("--trivia_test_qa_path", default=None, type=str, required=True)
-    p.add_argument("--max_tokens", default=131072, type=int)
+    p.add_argument("--max_tokens", default=adg.DRIVER_MAX_TOKENS, type=int)
     p.add_argument("--seed", default=None, type=int)
-    p.add_argument("--encoder_precision", default="split", choices=["fp16", "split", "fp32"],
+    p.add_argument("--encoder_precision", default=None, choices=["fp16", "split", "fp32"],
                    help="see ance_amd.ann_data_gen: split (default) is fp32-grade like the reference's forward, fp16 the fast mode")
     p.add_argument("--host_workers", default=None, type=int, help="has_answer worker processes on rank 0 (default: up to 32)")
     return p.parse_args(argv)

@@ -74,17 +74,9 @@ __device__ __forceinline__ f16x4 cvt_f16x4_pinned(const f32x4 v) {
 // elements are fp16 subnormals (kept by the conversion and by the MFMA: tests/test_gpu_gemm.py::test_mfma_keeps_f16_subnormals);
 // below 2^-24 they lose at most 2^-25 ABSOLUTE, which is why weights are stored times a per-matrix power of two that puts
 // their largest element in [2^13, 2^14) (encoder.hip: split_weight_kernel; undone in the GEMM epilogue).
-// ANCE_SPLIT_V1 (measurement builds only, `make splitv1`): round 4's format -- rows [hi (W) | lo' (W)], lo' = (v - hi) 2^11, three
-// K segments with a rescale in between -- for same-box A/B runs.
-#ifdef ANCE_SPLIT_V1
-constexpr float PAIR_LO_SCALE = 2048.0f, PAIR_LO_INV = 1.0f / 2048.0f;
-__host__ __device__ __forceinline__ int pair_hi_col(int n, int W) { (void)W; return n; }
-__host__ __device__ __forceinline__ int pair_lo_col(int n, int W) { return n + W; }
-#else
 constexpr float PAIR_LO_SCALE = 1.0f, PAIR_LO_INV = 1.0f;
 __host__ __device__ __forceinline__ int pair_hi_col(int n, int W) { (void)W; return ((n >> 5) << 6) + (n & 31); }
 __host__ __device__ __forceinline__ int pair_lo_col(int n, int W) { (void)W; return ((n >> 5) << 6) + (n & 31) + 32; }
-#endif
 // v (4 consecutive columns) -> the two f16x4 of its pair; the hi that is stored is the hi the residual was formed from
 __device__ __forceinline__ void pair_split4(const f32x4 v, f16x4 *hi, f16x4 *lo) {
 #pragma clang fp contract(off)
@@ -104,6 +96,26 @@ __device__ __forceinline__ f32x4 pair_load4(const _Float16 *row, int W, int n) {
     const f16x4 h = *reinterpret_cast<const f16x4 *>(row + pair_hi_col(n, W)), r = *reinterpret_cast<const f16x4 *>(row + pair_lo_col(n, W));
     return f32x4{(float)h[0] + (float)r[0] * PAIR_LO_INV, (float)h[1] + (float)r[1] * PAIR_LO_INV, (float)h[2] + (float)r[2] * PAIR_LO_INV,
                  (float)h[3] + (float)r[3] * PAIR_LO_INV};
+}
+
+// ---- range guard of the split mode (include/ance_amd.h: ance_encoder_range_faults) -------------------------------------------
+// The hi half of a pair is an fp16: a value above 65,504 in magnitude overflows it, where the reference's fp32 would carry on.  Every
+// pair-forming stage folds the magnitudes of what it stores into one running maximum per thread (v_max3_f32 with |.| source
+// modifiers: half an instruction per element; hipcc's fmaxf canonicalises its operands first -- twice the count) and reports once per
+// wave when the kernel ends.  A NaN operand is dropped by the maximum (IEEE mode returns the other operand): NaN rows are counted where
+// the output rows are written (encoder.hip: head kernels); an overflow is always seen here first -- it is finite or infinite before
+// anything turns into a NaN.
+constexpr float RANGE_LIMIT = 65504.0f;
+__device__ __forceinline__ void range_track4(const f32x4 v, float *mx) {
+    float m = *mx;
+    asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(m) : "v"(v[0]), "v"(v[1]));
+    asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(m) : "v"(v[2]), "v"(v[3]));
+    *mx = m;
+}
+// faults[0] += the number of lanes of this wave whose running maximum left the range (one atomic per wave, none in the normal case)
+__device__ __forceinline__ void range_report(float mx, unsigned *faults) {
+    const u64 bad = __builtin_amdgcn_ballot_w64(!(mx <= RANGE_LIMIT));
+    if (bad != 0 && faults != nullptr && (threadIdx.x & 63) == (unsigned)__builtin_ctzll(bad)) atomicAdd(faults, (unsigned)__builtin_popcountll(bad));
 }
 
 __device__ inline int lane_id() { return (int)(threadIdx.x & 63); }

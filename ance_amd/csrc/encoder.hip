@@ -305,7 +305,7 @@ __global__ void __launch_bounds__(256) gather_cls_kernel(const float *pre, const
 __global__ void __launch_bounds__(256) head_kernel(const float *pre, const _Float16 *hi, const _Float16 *lo, int ldp, int pair_w,
                                                    const float *stats, const float *part, float eps, const float *lng, const float *lnb,
                                                    const int *seq_off, int compact, const float *W, const float *b,
-                                                   const float *gamma, const float *beta, int has_head, float *out) {
+                                                   const float *gamma, const float *beta, int has_head, float *out, unsigned *faults) {
     __shared__ float cls[H];
     __shared__ float z[HEAD_OUT];
     __shared__ float red[8];
@@ -322,6 +322,8 @@ __global__ void __launch_bounds__(256) head_kernel(const float *pre, const _Floa
     };
     if (!has_head) {
         for (int j = tid; j < H; j += 256) dst[j] = (src(j) - mean_h) * rstd_h * lng[j] + lnb[j];
+        // a NaN anywhere in the row (or an infinity: rstd 0) shows in its statistics: count the row (ance_encoder_range_faults [1])
+        if (tid == 0 && faults && (!(fabsf(mean_h) < INFINITY) || !(rstd_h > 0.f && rstd_h < INFINITY))) atomicAdd(faults + 1, 1u);
         return;
     }
     for (int j = tid; j < H; j += 256) cls[j] = (src(j) - mean_h) * rstd_h * lng[j] + lnb[j];
@@ -356,6 +358,7 @@ __global__ void __launch_bounds__(256) head_kernel(const float *pre, const _Floa
     __syncthreads();
     const float rstd = rsqrtf((red[4] + red[5] + red[6] + red[7]) * (1.0f / HEAD_OUT) + 1e-5f);
     for (int j = tid; j < HEAD_OUT; j += 256) dst[j] = (z[j] - mean) * rstd * gamma[j] + beta[j];
+    if (tid == 0 && faults && (!(fabsf(mean) < INFINITY) || !(rstd > 0.f && rstd < INFINITY))) atomicAdd(faults + 1, 1u);
 }
 
 
@@ -462,10 +465,16 @@ __global__ void __launch_bounds__(256) fold_weight_kernel(const float *W, const 
 // ---- split mode ---------------------------------------------------------------------------------
 constexpr int HP = 2 * H;  // halves per pair row of a 768-wide stream (common.h: blocked [hi (32) | lo (32)] column blocks)
 
-// embeddings -> pair rows of the pre-LayerNorm stream + the slice statistics (format of EPI_S_RESLN); one wave per token
+// embeddings -> pair rows of the pre-LayerNorm stream + the slice statistics (format of EPI_S_RESLN); one wave per token.
+// The row is stored times EMB_SCALE: the lo half of a pair is unscaled (common.h), i.e. good to 2^-25 ABSOLUTE, which is fp32-grade for
+// the O(1) post-residual streams but not for an embedding sum of magnitude 0.05 (trained BERT / RoBERTa checkpoints) that a LayerNorm
+// with rstd ~ 20 then blows up.  A LayerNorm is scale-invariant up to its epsilon: the two consumers of this stream (layer
+// 0's Q | K | V GEMM and the residual of its attention-output GEMM) run with eps EMB_SCALE^2 -- powers of two, so (v s - mean s) and
+// rstd / s are the unscaled values' bits.
+constexpr float EMB_SCALE = 16.0f;
 __global__ void __launch_bounds__(256) embed_split_kernel(const int *tok_id, const int *tok_pos, int Tpad, const float *word,
                                                           const float *pos, const float *type0, int vocab, int max_pos,
-                                                          _Float16 *xp, float *part) {
+                                                          _Float16 *xp, float *part, unsigned *faults) {
     const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int l = threadIdx.x & 63;
     if (t >= Tpad) return;
@@ -475,10 +484,12 @@ __global__ void __launch_bounds__(256) embed_split_kernel(const int *tok_id, con
     const f32x4 *w4 = reinterpret_cast<const f32x4 *>(word + (size_t)id * H);
     const f32x4 *p4 = reinterpret_cast<const f32x4 *>(pos + (size_t)p * H);
     const f32x4 *t4 = reinterpret_cast<const f32x4 *>(type0);
+    float mx = 0.f;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         const int c4 = k * 64 + l;
-        const f32x4 v = (w4[c4] + t4[c4]) + p4[c4];  // same association as the reference: (word + type) + pos
+        const f32x4 v = ((w4[c4] + t4[c4]) + p4[c4]) * EMB_SCALE;  // same association as the reference: (word + type) + pos
+        range_track4(v, &mx);
         pair_store4(v, xp + (size_t)t * HP, H, c4 * 4);
         const float m64 = row16_sum((v[0] + v[1]) + (v[2] + v[3])) * (1.0f / 64.0f);
         const float d0 = v[0] - m64, d1 = v[1] - m64, d2 = v[2] - m64, d3 = v[3] - m64;
@@ -489,6 +500,7 @@ __global__ void __launch_bounds__(256) embed_split_kernel(const int *tok_id, con
             pp[1] = q64;
         }
     }
+    range_report(mx, faults);
 }
 
 // Per-matrix scale of the split GEMM's weights: s = 2^p with max |g (.) W| s in [2^13, 2^14).  Pair halves are UNSCALED differences
@@ -508,10 +520,6 @@ __global__ void __launch_bounds__(256) wabsmax_kernel(const float *W, const floa
     if ((threadIdx.x & 63) == 0 && m > 0.f && m < INFINITY) atomicMax(slot, __builtin_bit_cast(unsigned, m));
 }
 __device__ __forceinline__ float weight_pair_scale(const unsigned *slot) {
-#ifdef ANCE_SPLIT_V1
-    (void)slot;
-    return 1.0f;  // round 4: lo' carries its own 2^11, weights are stored as they are
-#else
     const float m = __builtin_bit_cast(float, *slot);
     if (!(m > 0.f)) return 1.0f;
     int e;
@@ -519,7 +527,6 @@ __device__ __forceinline__ float weight_pair_scale(const unsigned *slot) {
     int p = 14 - e;
     p = p < -60 ? -60 : (p > 60 ? 60 : p);
     return ldexpf(1.0f, p);
-#endif
 }
 
 // weight load for the split GEMM: row n of W [N, K] -> pair row (common.h) of  s (g (.) W)  (g = the LayerNorm weight folded in, or
@@ -642,7 +649,8 @@ __global__ void __launch_bounds__(256) head_gemm_kernel(const float *pre32, cons
 }
 
 // final LayerNorm (model/models.py:146,152 "norm") of the head output, in place; one wave per sequence
-__global__ void __launch_bounds__(256) head_ln_kernel(float *out, int S, const float *gamma, const float *beta) {
+// (a NaN anywhere upstream of a row -- or an infinity -- shows in these statistics: such rows are counted in faults[1])
+__global__ void __launch_bounds__(256) head_ln_kernel(float *out, int S, const float *gamma, const float *beta, unsigned *faults) {
     const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int l = threadIdx.x & 63;
     if (s >= S) return;
@@ -668,6 +676,7 @@ __global__ void __launch_bounds__(256) head_ln_kernel(float *out, int S, const f
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) q += __shfl_xor(q, off);
     const float rstd = rsqrtf(q * (1.0f / HEAD_OUT) + 1e-5f);
+    if (l == 0 && faults && (!(fabsf(mean) < INFINITY) || !(rstd > 0.f && rstd < INFINITY))) atomicAdd(faults + 1, 1u);
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         const int c4 = k * 64 + l;
@@ -677,8 +686,9 @@ __global__ void __launch_bounds__(256) head_ln_kernel(float *out, int S, const f
 
 // ------------------------------------------------------------------------------- host layout --
 
-// ANCE_ENCODER_PRECISE=1: handles created while it is set run the fp32 path of precise32.h (the arena and workspace sizes
-// grow by the fp32 weights and activations, so the size queries read the same switch)
+// AnceEncoderDesc.precision names the arithmetic of a handle; ANCE_PRECISION_DEFAULT defers to these environment switches.
+// ANCE_ENCODER_PRECISE=1: the fp32 path of precise32.h (the arena and workspace sizes grow by the fp32 weights and activations, so
+// the size queries resolve the mode the same way)
 bool precise_env() {
     const char *p = getenv("ANCE_ENCODER_PRECISE");
     return p && p[0] == '1';
@@ -697,6 +707,14 @@ bool split_env() {
     if (s && s[0] == '0') return false;
     const char *f = getenv("ANCE_ENCODER_FP16");
     return !(f && f[0] == '1');
+}
+
+// The arithmetic of a descriptor: AnceEncoderDesc.precision, or -- ANCE_PRECISION_DEFAULT -- what the environment says.
+int resolve_precision(const AnceEncoderDesc *d) {
+    if (d->precision == ANCE_PRECISION_SPLIT || d->precision == ANCE_PRECISION_FP16 || d->precision == ANCE_PRECISION_FP32)
+        return d->precision;
+    if (precise_env()) return ANCE_PRECISION_FP32;
+    return split_env() ? ANCE_PRECISION_SPLIT : ANCE_PRECISION_FP16;
 }
 
 struct LayerW {
@@ -736,6 +754,7 @@ struct AnceEncoder {
     // epilogue phases of the other
     int tcap, vcap, scap;
     int *lens_fetch;
+    unsigned *faults;  // device: [0] out-of-range stores of the split mode, [1] NaN output rows
     struct Lane {
         int *seq_off, *seq_vtcol, *seq_len, *tok_id, *tok_pos, *tok_vtcol;
         float *preA, *preB;      // pre-LayerNorm rows: attention block output / FFN block output (or embeddings)
@@ -767,12 +786,13 @@ namespace {
 bool desc_ok(const AnceEncoderDesc *d) {
     return d && d->hidden == H && d->n_heads == 12 && d->intermediate > 0 && d->intermediate % 128 == 0 &&
            d->n_layers >= 1 && d->vocab_size > 0 && d->max_position > 0 && d->max_seq_len >= 1 &&
-           d->max_seq_len <= 512 && d->max_tokens >= 512 && d->max_tokens % 256 == 0 &&
+           d->max_seq_len <= 512 && d->max_tokens >= 512 && d->max_tokens % 256 == 0 && d->precision >= 0 && d->precision <= 3 &&
            (d->arch == ANCE_ARCH_ROBERTA || d->arch == ANCE_ARCH_BERT);
 }
 
 void layout_weights(const AnceEncoderDesc *d, Arena &a, AnceEncoder *e) {
     const size_t I = d->intermediate;
+    const int mode = resolve_precision(d);
     float *word = a.take<float>((size_t)d->vocab_size * H);
     float *pos = a.take<float>((size_t)d->max_position * H);
     float *type0 = a.take<float>(H);
@@ -799,7 +819,7 @@ void layout_weights(const AnceEncoderDesc *d, Arena &a, AnceEncoder *e) {
         w.c1 = a.take<float>(I);
         w.wqkv_s = w.wo_s = w.w1_s = w.w2_s = nullptr;
         w.bqkv_s = w.cqkv_s = w.b1_s = w.c1_s = w.sc_s = nullptr;
-        if (split_env()) {
+        if (mode == ANCE_PRECISION_SPLIT) {
             w.sc_s = a.take<float>(8);
             w.wqkv_s = a.take<_Float16>((size_t)3 * H * HP);
             w.bqkv_s = a.take<float>(3 * H);
@@ -811,7 +831,7 @@ void layout_weights(const AnceEncoderDesc *d, Arena &a, AnceEncoder *e) {
             w.w2_s = a.take<_Float16>((size_t)H * 2 * I);
         }
         w.wqkv32 = w.bqkv32 = w.wo32 = w.w132 = w.w232 = nullptr;
-        if (precise_env()) {
+        if (mode == ANCE_PRECISION_FP32) {
             w.wqkv32 = a.take<float>((size_t)3 * H * H);
             w.bqkv32 = a.take<float>(3 * H);
             w.wo32 = a.take<float>((size_t)H * H);
@@ -834,9 +854,11 @@ void layout_workspace(const AnceEncoderDesc *d, Arena &a, AnceEncoder *e) {
     const int tcap = d->max_tokens;
     const int scap = tcap < S_CAP_MAX ? tcap : S_CAP_MAX;
     const int vcap = (int)align_up((size_t)tcap + tcap / 4 + 256, 256);
+    const int mode = resolve_precision(d);
+    unsigned *faults = a.take<unsigned>(64);  // [0] out-of-range stores of the split mode, [1] NaN output rows (ance_encoder_range_faults)
     int *lens_fetch = a.take<int>(FETCH_CHUNK);
     if (e) {
-        e->tcap = tcap; e->scap = scap; e->vcap = vcap; e->lens_fetch = lens_fetch;
+        e->tcap = tcap; e->scap = scap; e->vcap = vcap; e->lens_fetch = lens_fetch; e->faults = faults;
     }
     for (int ln = 0; ln < MAX_LANES; ++ln) {
         AnceEncoder::Lane L;
@@ -853,11 +875,11 @@ void layout_workspace(const AnceEncoderDesc *d, Arena &a, AnceEncoder *e) {
         L.partA = a.take<float>((size_t)tcap * (H / 64) * 2);
         L.partB = a.take<float>((size_t)tcap * (H / 64) * 2);
         L.x32 = L.xa32 = L.qkv32 = L.ctx32 = L.ffn32 = nullptr;
-        if (precise_env()) {
+        if (mode == ANCE_PRECISION_FP32) {
             L.x32 = a.take<float>((size_t)tcap * H);
             L.xa32 = a.take<float>((size_t)tcap * H);
         }
-        if (precise_env() || split_env()) {
+        if (mode == ANCE_PRECISION_FP32 || mode == ANCE_PRECISION_SPLIT) {
             // split mode: qkv32 = fp32 Q | K | V; ctx32 / ffn32 hold the PAIR rows of the attention output / FFN activation
             // (an fp16 pair row is as many bytes as the fp32 row)
             L.qkv32 = a.take<float>((size_t)tcap * 3 * H);
@@ -1019,11 +1041,11 @@ int encode_impl(AnceEncoder *e, const int32_t *base, int64_t ld, const int32_t *
                         hipLaunchKernelGGL(head_gemm_kernel, dim3((S + 31) / 32, HEAD_OUT / 128), dim3(256), HEAD_LDS_BYTES, st, LN.preB,
                                            (const _Float16 *)nullptr, (const _Float16 *)nullptr, H, 0, LN.statsB, (const float *)nullptr,
                                            D.ln_eps, WL.ln2w, WL.ln2b, LN.seq_off, 0, S, e->head_w, e->head_b, dst);
-                        hipLaunchKernelGGL(head_ln_kernel, dim3((S + 3) / 4), dim3(256), 0, st, dst, S, e->norm_w, e->norm_b);
+                        hipLaunchKernelGGL(head_ln_kernel, dim3((S + 3) / 4), dim3(256), 0, st, dst, S, e->norm_w, e->norm_b, e->faults);
                     } else {
                         hipLaunchKernelGGL(head_kernel, dim3(S), dim3(256), 0, st, LN.preB, (const _Float16 *)nullptr,
                                            (const _Float16 *)nullptr, H, 0, LN.statsB, (const float *)nullptr, D.ln_eps, WL.ln2w, WL.ln2b,
-                                           LN.seq_off, 0, e->head_w, e->head_b, e->norm_w, e->norm_b, 0, dst);
+                                           LN.seq_off, 0, e->head_w, e->head_b, e->norm_w, e->norm_b, 0, dst, e->faults);
                     }
                 }
                 gs = g;
@@ -1036,7 +1058,7 @@ int encode_impl(AnceEncoder *e, const int32_t *base, int64_t ld, const int32_t *
                 {
                     ProfScope pe(PC_EMBED, st);
                     hipLaunchKernelGGL(embed_split_kernel, dim3(Tpad / 4), dim3(256), 0, st, LN.tok_id, LN.tok_pos, Tpad, e->word,
-                                       e->pos, e->type0, D.vocab_size, D.max_position, xb, LN.partB);
+                                       e->pos, e->type0, D.vocab_size, D.max_position, xb, LN.partB, e->faults);
                 }
                 const bool cls_tail = e->cls_tail;
                 const int S_pad = (int)align_up((size_t)S, 256);
@@ -1046,12 +1068,14 @@ int encode_impl(AnceEncoder *e, const int32_t *base, int64_t ld, const int32_t *
                     const bool tail = cls_tail && li == D.n_layers - 1;
                     const int Mrows = tail ? S_pad : Tpad;
                     const double Mwork = tail ? (double)S : (double)T;
+                    // layer 0 reads the embedding stream, stored times EMB_SCALE: its LayerNorm runs with eps EMB_SCALE^2 (embed_split_kernel)
+                    const float eps_b = li == 0 ? D.ln_eps * (EMB_SCALE * EMB_SCALE) : D.ln_eps;
                     GemmArgs G;
                     memset(&G, 0, sizeof(G));
                     // Q | K | V projection -> fp32 (the LayerNorm that produces this layer's input is folded in)
                     G.A = xb; G.lda = HP; G.B = W.wqkv_s; G.ldb = HP; G.M = Tpad; G.N = 3 * H; G.K = H;
-                    G.bias = W.bqkv_s; G.csum = W.cqkv_s; G.part_in = LN.partB; G.ln_eps = D.ln_eps;
-                    G.out32 = LN.qkv32; G.ldc = 3 * H; G.wscale_inv = W.sc_s + 4;
+                    G.bias = W.bqkv_s; G.csum = W.cqkv_s; G.part_in = LN.partB; G.ln_eps = eps_b;
+                    G.out32 = LN.qkv32; G.ldc = 3 * H; G.wscale_inv = W.sc_s + 4; G.range_faults = e->faults;
                     {
                         ProfScope ps(PC_GEMM_QK, st, 2.0 * T * (3.0 * H) * H);
                         rc = launch_gemm_f16(EPI_S_QKV, G, st);
@@ -1071,7 +1095,7 @@ int encode_impl(AnceEncoder *e, const int32_t *base, int64_t ld, const int32_t *
                     memset(&G, 0, sizeof(G));
                     G.res_gamma = li == 0 ? e->eln_w : e->layers[li - 1].ln2w;
                     G.res_beta = li == 0 ? e->eln_b : e->layers[li - 1].ln2b;
-                    G.res_hi = xb; G.ldr = HP; G.part_in = LN.partB; G.ln_eps = D.ln_eps;
+                    G.res_hi = xb; G.ldr = HP; G.part_in = LN.partB; G.ln_eps = eps_b; G.range_faults = e->faults;
                     if (tail) {  // compact pair rows + partials of the [CLS] tokens, parked in the (currently dead) FFN buffer
                         float *cpt = reinterpret_cast<float *>(ffnp + (size_t)S_pad * HP);
                         ProfScope ps(PC_LN, st);
@@ -1091,6 +1115,7 @@ int encode_impl(AnceEncoder *e, const int32_t *base, int64_t ld, const int32_t *
                     G.A = xa; G.lda = HP; G.B = W.w1_s; G.ldb = HP; G.M = Mrows; G.N = I; G.K = H;
                     G.bias = W.b1_s; G.csum = W.c1_s; G.part_in = LN.partA; G.ln_eps = D.ln_eps;
                     G.out16 = ffnp; G.ldc = 2 * I; G.n_split = (e->n_split && (I / 256) % 2 == 0) ? 2 : 0; G.wscale_inv = W.sc_s + 6;
+                    G.range_faults = e->faults;
                     {
                         ProfScope ps(PC_GEMM_FFN1, st, 2.0 * Mwork * (double)I * H);
                         rc = launch_gemm_f16(EPI_S_GELU, G, st);
@@ -1101,6 +1126,7 @@ int encode_impl(AnceEncoder *e, const int32_t *base, int64_t ld, const int32_t *
                     G.A = ffnp; G.lda = 2 * I; G.B = W.w2_s; G.ldb = 2 * I; G.M = Mrows; G.N = H; G.K = I;
                     G.bias = W.b2; G.res_gamma = W.ln1w; G.res_beta = W.ln1b; G.res_hi = xa; G.ldr = HP;
                     G.part_in = LN.partA; G.ln_eps = D.ln_eps; G.out16 = xb; G.ldc = HP; G.part_out = LN.partB; G.wscale_inv = W.sc_s + 7;
+                    G.range_faults = e->faults;
                     {
                         ProfScope ps(PC_GEMM_FFN2, st, 2.0 * Mwork * (double)I * H);
                         rc = launch_gemm_f16(EPI_S_RESLN, G, st);
@@ -1116,12 +1142,12 @@ int encode_impl(AnceEncoder *e, const int32_t *base, int64_t ld, const int32_t *
                                            (const float *)nullptr, (const _Float16 *)xb, (const _Float16 *)nullptr, HP, H,
                                            (const float *)nullptr, (const float *)LN.partB, D.ln_eps, WL.ln2w, WL.ln2b, LN.seq_off,
                                            cls_tail ? 1 : 0, S, e->head_w, e->head_b, dst);
-                        hipLaunchKernelGGL(head_ln_kernel, dim3((S + 3) / 4), dim3(256), 0, st, dst, S, e->norm_w, e->norm_b);
+                        hipLaunchKernelGGL(head_ln_kernel, dim3((S + 3) / 4), dim3(256), 0, st, dst, S, e->norm_w, e->norm_b, e->faults);
                     } else {
                         hipLaunchKernelGGL(head_kernel, dim3(S), dim3(256), 0, st, (const float *)nullptr, (const _Float16 *)xb,
                                            (const _Float16 *)nullptr, HP, H, (const float *)nullptr, (const float *)LN.partB,
                                            D.ln_eps, WL.ln2w, WL.ln2b, LN.seq_off, cls_tail ? 1 : 0, e->head_w, e->head_b, e->norm_w,
-                                           e->norm_b, 0, dst);
+                                           e->norm_b, 0, dst, e->faults);
                     }
                 }
                 gs = g;
@@ -1262,11 +1288,11 @@ int encode_impl(AnceEncoder *e, const int32_t *base, int64_t ld, const int32_t *
                     hipLaunchKernelGGL(head_gemm_kernel, dim3((S + 31) / 32, HEAD_OUT / 128), dim3(256), HEAD_LDS_BYTES, st, LN.preB, hh,
                                        hl, H, 0, LN.statsB, fold ? LN.partB : (const float *)nullptr, D.ln_eps, WL.ln2w, WL.ln2b, LN.seq_off,
                                        cls_tail ? 1 : 0, S, e->head_w, e->head_b, dst);
-                    hipLaunchKernelGGL(head_ln_kernel, dim3((S + 3) / 4), dim3(256), 0, st, dst, S, e->norm_w, e->norm_b);
+                    hipLaunchKernelGGL(head_ln_kernel, dim3((S + 3) / 4), dim3(256), 0, st, dst, S, e->norm_w, e->norm_b, e->faults);
                 } else {
                     hipLaunchKernelGGL(head_kernel, dim3(S), dim3(256), 0, st, LN.preB, hh, hl, H, 0, LN.statsB,
                                        fold ? LN.partB : (const float *)nullptr, D.ln_eps, WL.ln2w, WL.ln2b, LN.seq_off,
-                                       cls_tail ? 1 : 0, e->head_w, e->head_b, e->norm_w, e->norm_b, D.has_head, dst);
+                                       cls_tail ? 1 : 0, e->head_w, e->head_b, e->norm_w, e->norm_b, D.has_head, dst, e->faults);
                 }
             }
             gs = g;
@@ -1334,8 +1360,9 @@ extern "C" int ance_encoder_create(const AnceEncoderDesc *desc, const void *cons
         e->head_mfma = !(hm && hm[0] == '0');
         const char *ac = getenv("ANCE_ATTN_COAL");
         e->attn_coal = !(ac && ac[0] == '0');
-        e->precise = precise_env();
-        e->split = split_env();
+        const int mode = resolve_precision(desc);
+        e->precise = mode == ANCE_PRECISION_FP32;
+        e->split = mode == ANCE_PRECISION_SPLIT;
         if (e->precise || e->split) e->ln_fold = false;  // these paths take the plain biases and LayerNorm parameters
         const char *nsp = getenv("ANCE_GEMM_NSPLIT");
         e->n_split = !(nsp && nsp[0] == '0');
@@ -1477,6 +1504,23 @@ extern "C" void ance_encoder_destroy(AnceEncoder *enc) {
     }
     if (enc->ev_fork) (void)hipEventDestroy(enc->ev_fork);
     delete enc;
+}
+
+extern "C" int ance_encoder_precision(const AnceEncoder *enc) {
+    if (!enc) return ANCE_E_INVALID;
+    return enc->precise ? ANCE_PRECISION_FP32 : enc->split ? ANCE_PRECISION_SPLIT : ANCE_PRECISION_FP16;
+}
+
+extern "C" int ance_encoder_range_faults(AnceEncoder *enc, uint32_t *h_out, int reset, void *stream) {
+    if (!enc || !h_out) {
+        set_last_error("ance_encoder_range_faults: invalid argument");
+        return ANCE_E_INVALID;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemcpyAsync(h_out, enc->faults, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st) != hipSuccess)
+        return check_launch("ance_encoder_range_faults");
+    if (reset) (void)hipMemsetAsync(enc->faults, 0, 2 * sizeof(uint32_t), st);
+    return check_launch("ance_encoder_range_faults");
 }
 
 extern "C" int ance_encode_records(AnceEncoder *enc, const void *d_records, const int32_t *h_lens, int64_t n, int L,

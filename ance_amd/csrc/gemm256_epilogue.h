@@ -462,6 +462,7 @@ __device__ __forceinline__ void gemm256_epilogue_split(const GemmArgs &G, f32x16
     f32x4 v2 = {0.f, 0.f, 0.f, 0.f};
     if constexpr (EPI == EPI_S_RESLN) v2 = *reinterpret_cast<const f32x4 *>(pb + EPB_VEC + 512 + wn * 64 + c4 * 4);  // beta
     const int n_parts = G.N >> 6, slice = nw0 >> 6;
+    float vmax = 0.f;  // range guard: running maximum of |what this thread stores| (common.h)
 #pragma unroll
     for (int y = 0; y < 4; ++y) {
         f16x4 rh[8], rl[8];
@@ -501,6 +502,7 @@ __device__ __forceinline__ void gemm256_epilogue_split(const GemmArgs &G, f32x16
                     const float res = (float)rh[it][e] + (float)rl[it][e] * PAIR_LO_INV;  // exact in fp32: 22 bits
                     v[e] = __builtin_fmaf(v[e], winv, __builtin_fmaf(res - mean[it], a, v0[e] + v2[e]));
                 }
+                range_track4(v, &vmax);
                 EPI_PAIR_STORE(v, G.out16 + row * G.ldc, G.N, nw0 + c4 * 4);
                 vv[it] = v;
             } else {
@@ -508,10 +510,12 @@ __device__ __forceinline__ void gemm256_epilogue_split(const GemmArgs &G, f32x16
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(v[e], rw, __builtin_fmaf(-mr, v1[e], v0[e]));
                 if constexpr (EPI == EPI_S_QKV) {
+                    range_track4(v, &vmax);  // the attention splits K and V into pairs while it stages them
                     EPI_F32_STORE(reinterpret_cast<f32x4 *>(G.out32 + row * G.ldc + nw0 + c4 * 4), v);
                 } else {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = gelu_exact(v[e]);
+                    range_track4(v, &vmax);
                     EPI_PAIR_STORE(v, G.out16 + row * G.ldc, G.N, nw0 + c4 * 4);
                 }
             }
@@ -534,6 +538,7 @@ __device__ __forceinline__ void gemm256_epilogue_split(const GemmArgs &G, f32x16
             }
         }
     }
+    range_report(vmax, G.range_faults);
 }
 
 }  // namespace ance

@@ -281,12 +281,7 @@ __global__ void __launch_bounds__(G256_THREADS, 2) gemm256_split_kernel(const Ge
     for (int x = 0; x < 2; ++x)
 #pragma unroll
         for (int y = 0; y < 4; ++y) acc[x][y] = f32x16{0};
-#ifdef ANCE_SPLIT_V1
-    // round 4 (A/B builds): rows [hi (K) | lo' (K)], three K segments lo' x hi, hi x lo', hi x hi, one 2^-11 rescale in between
-    Pipe256T<PipeSrcSplit, false, true, true> P;
-#else
     Pipe256T<PipeSrcDesc, false, true, true, true> P;
-#endif
     P.init(smem, w, l);
     P.S.ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16 *>(G.A + (size_t)m0 * G.lda), 0, (int)(256u * (uint32_t)G.lda * 2u), 0x00020000);
     P.S.rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16 *>(G.B + (size_t)n0 * G.ldb), 0, (int)(256u * (uint32_t)G.ldb * 2u), 0x00020000);
@@ -304,22 +299,7 @@ __global__ void __launch_bounds__(G256_THREADS, 2) gemm256_split_kernel(const Ge
 #endif
     GSTAMP(0);
     epb_issue<EPI>(G, smem_f, m0, n0, w, l);
-#ifdef ANCE_SPLIT_V1
-    const int NK = G.K / TK;
-    P.S.nk = NK;
-    P.S.kbytes = G.K * 2;
-    P.prologue();
-    P.enter();
-    P.tiles_streaming(2 * NK, acc);   // the two correction segments (both carry the factor 2^11)
-#pragma unroll
-    for (int x = 0; x < 2; ++x)
-#pragma unroll
-        for (int y = 0; y < 4; ++y) acc[x][y] *= PAIR_LO_INV;
-    P.tiles_final(3 * NK, acc, 2 * NK);  // hi x hi
-    P.leave();
-#else
     P.run(G.K / 32, acc);  // K-tile = 64 halves of a blocked pair row = 32 k of hi and lo
-#endif
     GSTAMP(1);
     (void)epb_stats(G, smem_f, tid);
     GSTAMP(2);

@@ -53,6 +53,7 @@ struct GemmArgs {
     // power of two the B operand (the weight) was stored with, or null (1)
     int ldr;
     const float *wscale_inv;
+    unsigned *range_faults;  // split epilogues: sticky counter of threads that stored a value outside the fp16 range (common.h: range_report), or null
     int n_split;         // 2: N-split tile order (gemm256_f16.hip: tile_of_block; desc / split kernels only, N / 256 even); else 0
     int debug_mode;      // ance_debug_gemm ablations: 1 = no loads after tile 0, 2 = no MFMA, 4 = all blocks load tile (0,0)
 };

@@ -441,6 +441,16 @@ extern "C" int ance_ip_topk(const float *d_x, int64_t n, int64_t row_base, const
     return ip_topk_exact_scan(d_x, n, row_base, d_q, nq, d, k, d_out_d, d_out_i, d_workspace, workspace_bytes, stream);
 }
 
+// the fp32-MFMA scan alone, whatever the shape and the environment: the audit path of the two-precision kernel
+extern "C" size_t ance_ip_topk_scan_workspace_bytes(int64_t n, int64_t nq, int d, int k) {
+    (void)d;
+    return scan_workspace_bytes(n, nq, k);
+}
+extern "C" int ance_ip_topk_scan(const float *d_x, int64_t n, int64_t row_base, const float *d_q, int64_t nq, int d, int k,
+                                 float *d_out_d, int64_t *d_out_i, void *d_workspace, size_t workspace_bytes, void *stream) {
+    return ip_topk_exact_scan(d_x, n, row_base, d_q, nq, d, k, d_out_d, d_out_i, d_workspace, workspace_bytes, stream);
+}
+
 extern "C" size_t ance_ip_index_bytes(int64_t n, int d) { return fast_enabled() ? ip_index_bytes(n, d) : 0; }
 
 extern "C" int ance_ip_index_build(const float *d_x, int64_t n, int d, void *d_index, size_t index_bytes, void *stream) {

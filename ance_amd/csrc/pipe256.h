@@ -102,27 +102,6 @@ struct PipeSrcDesc {
     }
 };
 
-// Source policy of the SPLIT (fp32-grade) GEMM: every operand row is an fp16 pair  [hi (K halves) | lo' (K halves)],
-// v = hi + lo' 2^-11 (row stride 2 K), and the K loop runs over 3 K / 64 tiles in three segments
-//   tiles [0, nk)      A lo' x B hi   \  accumulated first, then the accumulators are scaled by 2^-11 once
-//   tiles [nk, 2 nk)   A hi  x B lo'  /
-//   tiles [2 nk, 3 nk) A hi  x B hi
-// The segment only changes the SGPR byte offset of the LDS-DMA (wave-uniform scalar arithmetic on the loop counter): the
-// pipeline streams across the segment borders without draining.
-struct PipeSrcSplit {
-    __amdgpu_buffer_rsrc_t ra, rb;
-    uint32_t voff[4][2];  // [A0 A1 B0 B1][piece]
-    int nk;               // K / 64
-    int kbytes;           // 2 K: byte offset of the lo' half of a row
-    template <int TYPE, int J>
-    __device__ __forceinline__ void issue(int t, pipe_lds_t *dst) const {
-        const int seg = (t >= nk) + (t >= 2 * nk);
-        const bool lo = TYPE < 2 ? seg == 0 : seg == 1;
-        const int soff = (t - seg * nk) * 128 + (lo ? kbytes : 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(TYPE < 2 ? ra : rb, dst, 16, voff[TYPE][J], soff, 0, 0);
-    }
-};
-
 // SRC provides  template <int TYPE, int J> void issue(int t, pipe_lds_t *dst)  : the LDS-DMA (16 bytes per lane, 1 KiB per
 // wave, lane-linear at dst) of piece J of half-tile TYPE (0 A-half0, 1 A-half1, 2 B-half0, 3 B-half1) of K-tile t.
 // DBG compiles measurement ablations in (dbg bit 1: no MFMA, bit 3: no staging); product code uses DBG = false.

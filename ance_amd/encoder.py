@@ -55,31 +55,9 @@ def count_layers(state_dict, prefix):
     return n
 
 
-import contextlib
-
-
-@contextlib.contextmanager
-def _precision_env(env):
-    """The library reads the encoder mode from the environment when a handle is created (include/ance_amd.h): set exactly
-    ``env`` (a dict, or None = leave the environment as it is) for the duration of the create call.  One host thread per GPU
-    process, like the rest of the binding."""
-    if env is None:
-        yield
-        return
-    keys = ("ANCE_ENCODER_SPLIT", "ANCE_ENCODER_PRECISE", "ANCE_ENCODER_FP16")
-    saved = {k: os.environ.pop(k, None) for k in keys}
-    os.environ.update(env)
-    try:
-        yield
-    finally:
-        for k in keys:
-            os.environ.pop(k, None)
-            if saved[k] is not None:
-                os.environ[k] = saved[k]
-
-
 def precision_from_env(env=None):
-    """The mode a handle created now would run (the rule of csrc/encoder.hip: split_env / precise_env)."""
+    """The mode a handle created with ``precision=None`` (AnceEncoderDesc.precision = ANCE_PRECISION_DEFAULT) would run: the rule of
+    csrc/encoder.hip: resolve_precision."""
     env = os.environ if env is None else env
     if env.get("ANCE_ENCODER_PRECISE", "")[:1] == "1":
         return "fp32"
@@ -95,30 +73,35 @@ def _written_through_raw_pointer(t):
     """The library wrote ``t`` through its data pointer: bump the tensor's version counter, which is what
     ``FlatIPIndex`` keys its search image on -- re-encoding into a buffer that was searched rebuilds the image."""
     import torch
+    if t.is_inference():
+        # tensors created under torch.inference_mode() carry no version counter: their holder must call
+        # FlatIPIndex.invalidate() after re-encoding into a buffer that was searched
+        return
     torch.autograd.graph.increment_version(t)
 
 
 class Encoder:
     """One transformer tower + (optional) ANCE head resident in HBM."""
 
-    PRECISIONS = {"fp16": {"ANCE_ENCODER_FP16": "1"}, "split": {"ANCE_ENCODER_SPLIT": "1"}, "fp32": {"ANCE_ENCODER_PRECISE": "1"}}
+    PRECISIONS = ("split", "fp16", "fp32")
 
     def __init__(self, state_dict, arch=ARCH_ROBERTA, prefix="roberta.", has_head=True, pad_token_id=None,
-                 ln_eps=None, max_seq_len=512, max_tokens=131072, device=None, precision=None):
-        """precision: None = whatever the environment says (include/ance_amd.h) -- with nothing set that is "split", the
-        library's default: fp16-pair operands on the fp16 matrix cores, fp32-grade like the reference's own fp32 forward (2e-5;
-        the mode in which the refresh reproduces the reference's negative ids).  "fp16" = the fast mode (fp16 MFMA operands,
-        3e-3 on the embeddings, ~2.2 x the throughput; ANCE_ENCODER_FP16=1), "fp32" = fp32 operands (the audit path, ~3.5 x
-        slower than split; ANCE_ENCODER_PRECISE=1).  The library reads the mode when the handle is created."""
+                 ln_eps=None, max_seq_len=512, max_tokens=65536, device=None, precision=None):
+        """precision: the arithmetic of the handle (AnceEncoderDesc.precision, include/ance_amd.h).  None = whatever the
+        environment says -- with nothing set that is "split", the library's default: fp16-pair operands on the fp16 matrix cores,
+        fp32-grade like the reference's own fp32 forward (2e-5; the mode in which the refresh reproduces the reference's negative
+        ids).  "fp16" = the fast mode (fp16 MFMA operands, 3e-3 on the embeddings, ~2.2 x the throughput), "fp32" = fp32 operands
+        (the audit path, ~4.4 x slower than split).
+        max_tokens: token capacity of one micro-batch; the activation workspace scales with it -- split mode: 2.8 GB per 65,536
+        tokens and lane, two lanes (the refresh drivers and bench.py pass 131,072: +1.3 % throughput for 11 GB per tower)."""
         import torch
         L = _lib.lib()
         if precision is not None and precision not in self.PRECISIONS:
             raise ValueError("precision must be one of %s" % sorted(self.PRECISIONS))
-        with _precision_env(self.PRECISIONS.get(precision)):
-            self._create(L, torch, state_dict, arch, prefix, has_head, pad_token_id, ln_eps, max_seq_len, max_tokens, device)
+        self._create(L, torch, state_dict, arch, prefix, has_head, pad_token_id, ln_eps, max_seq_len, max_tokens, device,
+                     _lib.PRECISION_CODES[precision])
 
-    def _create(self, L, torch, state_dict, arch, prefix, has_head, pad_token_id, ln_eps, max_seq_len, max_tokens, device):
-        self.precision = precision_from_env()
+    def _create(self, L, torch, state_dict, arch, prefix, has_head, pad_token_id, ln_eps, max_seq_len, max_tokens, device, precision_code):
         self.device = torch.device(device if device is not None else "cuda")
         n_layers = count_layers(state_dict, prefix)
         if n_layers == 0:
@@ -137,7 +120,7 @@ class Encoder:
             pad_token_id=(1 if arch == ARCH_ROBERTA else 0) if pad_token_id is None else int(pad_token_id),
             ln_eps=(1e-5 if arch == ARCH_ROBERTA else 1e-12) if ln_eps is None else float(ln_eps),
             has_head=1 if has_head else 0, max_seq_len=int(max_seq_len),
-            max_tokens=max(512, int(max_tokens) // 256 * 256))
+            max_tokens=max(512, int(max_tokens) // 256 * 256), precision=precision_code)
         wbytes = L.ance_encoder_weight_bytes(ctypes.byref(self.desc))
         xbytes = L.ance_encoder_workspace_bytes(ctypes.byref(self.desc))
         if wbytes == 0 or xbytes == 0:
@@ -155,8 +138,13 @@ class Encoder:
             torch.cuda.current_stream().synchronize()  # fp32 sources may now be released
         del staged
         self._h = handle
+        self.precision = _lib.PRECISION_NAMES[L.ance_encoder_precision(handle)]
         self.n_layers = n_layers
         self.out_dim = 768
+        # range guard (include/ance_amd.h: ance_encoder_range_faults): the counters are copied to pinned memory behind every encode
+        # call and looked at without synchronising when the next call starts; check_range(sync=True) is the blocking form
+        self._faults = torch.zeros(2, dtype=torch.int32).pin_memory()
+        self._faults_event = None
 
     def __del__(self):
         h = getattr(self, "_h", None)
@@ -166,6 +154,35 @@ class Encoder:
             except Exception:
                 pass
             self._h = None
+
+    # -- range guard -------------------------------------------------------------------------------------
+    def _enqueue_range_read(self):
+        import torch
+        rc = _lib.lib().ance_encoder_range_faults(self._h, ctypes.c_void_p(self._faults.data_ptr()), 0, _lib.current_stream_ptr())
+        _lib.check(rc, "ance_encoder_range_faults")
+        ev = torch.cuda.Event()
+        ev.record()
+        self._faults_event = ev
+
+    def check_range(self, sync=False):
+        """Raises ``AnceRangeError`` when an encode call whose counters have arrived (``sync``: of every call so far) violated the
+        split mode's precondition -- a pre-LayerNorm value, Q | K | V entry or GELU output above 65,504, where the reference's fp32
+        has no limit -- or produced NaN rows.  Sticky: the handle keeps failing; build one with ``precision="fp32"``
+        (``--encoder_precision fp32``) for such a checkpoint."""
+        ev = self._faults_event
+        if ev is None:
+            return
+        if sync:
+            ev.synchronize()
+        elif not ev.query():
+            return
+        over, nan_rows = int(self._faults[0]), int(self._faults[1])
+        if over or nan_rows:
+            raise _lib.AnceRangeError(
+                "encoder range guard (%s mode): %d threads stored values above 65,504 in magnitude (the hi half of an fp16 pair "
+                "overflows there; the reference's fp32 arithmetic has no such limit), %d output rows are NaN -- these embeddings "
+                "are not fp32-grade: run this checkpoint with --encoder_precision fp32 (Encoder(precision=\"fp32\"))"
+                % (self.precision, over, nan_rows))
 
     # -- raw-record path: what the refresh job uses ------------------------------------------------
     def encode_records(self, records, n_chunks=1, h_lens=None, out=None):
@@ -187,10 +204,12 @@ class Encoder:
             h_lens = np.ascontiguousarray(h_lens, dtype=np.int32)
             assert h_lens.shape[0] == n
             hl = h_lens.ctypes.data_as(ctypes.c_void_p)
+        self.check_range()
         with torch.cuda.device(self.device):
             rc = _lib.lib().ance_encode_records(self._h, ctypes.c_void_p(records.data_ptr()), hl, n, Ltok, n_chunks,
                                                 ctypes.c_void_p(out.data_ptr()), _lib.current_stream_ptr())
-        _lib.check(rc, "ance_encode_records")
+            _lib.check(rc, "ance_encode_records")
+            self._enqueue_range_read()
         _written_through_raw_pointer(out)
         return out
 
@@ -206,11 +225,13 @@ class Encoder:
         if h_lens is not None:
             h_lens = np.ascontiguousarray(h_lens, dtype=np.int32)
             hl = h_lens.ctypes.data_as(ctypes.c_void_p)
+        self.check_range()
         with torch.cuda.device(self.device):
             rc = _lib.lib().ance_encode_ids(self._h, ctypes.c_void_p(ids.data_ptr()), Ltok, ctypes.c_void_p(lens.data_ptr()),
                                             hl, n, Ltok, n_chunks, ctypes.c_void_p(out.data_ptr()),
                                             _lib.current_stream_ptr())
-        _lib.check(rc, "ance_encode_ids")
+            _lib.check(rc, "ance_encode_ids")
+            self._enqueue_range_read()
         _written_through_raw_pointer(out)
         return out
 
@@ -302,7 +323,7 @@ def load_hf_state_dict(ckpt_dir):
     raise FileNotFoundError("no model.safetensors / pytorch_model.bin in %s" % ckpt_dir)
 
 
-def load_model(model_type, checkpoint_path, max_seq_length=128, max_tokens=131072, device=None, precision=None):
+def load_model(model_type, checkpoint_path, max_seq_length=128, max_tokens=65536, device=None, precision=None):
     """Registry of model/models.py:299-322 restricted to the encoders on the path.  precision: see ``Encoder``."""
     model_type = model_type.lower()
     if model_type in ("rdot_nll", "rdot_nll_multi_chunk"):

@@ -127,7 +127,9 @@ class FlatIPIndex:
             torch.cuda.current_stream(self.device).wait_event(self._image_event)
         return self._image if self._image is not False else None
 
-    def search_device(self, qd, k):
+    def search_device(self, qd, k, exact_scan=False):
+        """exact_scan: answer with the fp32-MFMA scan alone (``ance_ip_topk_scan``) -- the independent audit path of the
+        two-precision kernel: same bits, ~7 x slower, no search image."""
         import torch
         L = _lib.lib()
         x = self._matrix()
@@ -137,6 +139,18 @@ class FlatIPIndex:
         D = torch.empty((nq, k), dtype=torch.float32, device=self.device)
         I = torch.empty((nq, k), dtype=torch.int64, device=self.device)
         if nq == 0:
+            return D, I
+        if exact_scan:
+            need = L.ance_ip_topk_scan_workspace_bytes(n, nq, self.dp, k)
+            if need == 0:
+                raise _lib.AnceLibraryError("ance_ip_topk_scan: unsupported (n=%d, nq=%d, k=%d)" % (n, nq, k))
+            ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+            with torch.cuda.device(self.device):
+                rc = L.ance_ip_topk_scan(ctypes.c_void_p(x.data_ptr() if n else 0), n, self.row_base, ctypes.c_void_p(qd.data_ptr()),
+                                         nq, self.dp, k, ctypes.c_void_p(D.data_ptr()), ctypes.c_void_p(I.data_ptr()),
+                                         ctypes.c_void_p(ws.data_ptr()), ws.numel(), _lib.current_stream_ptr())
+            _lib.check(rc, "ance_ip_topk_scan")
+            ws.record_stream(torch.cuda.current_stream(self.device))
             return D, I
         img = self._search_image(L, x)
         if img is not None:

@@ -68,6 +68,12 @@ def parse():
     p.add_argument("--full-queries", type=int, default=N_TRAIN_QUERIES)
     p.add_argument("--full-dev-queries", type=int, default=6980)
     p.add_argument("--negative-sample", type=int, default=20)
+    p.add_argument("--skip-other-configs", action="store_true",
+                   help="skip the encode legs of BASELINE configs[2..4] (L=512, MaxP 4x512, DPR BERT L=256)")
+    p.add_argument("--other-config-steps", type=int, default=3, help="timed steps of each other-config leg (at most 6)")
+    p.add_argument("--other-config-tokens", type=int, default=1 << 20, help="real tokens per step of each other-config leg")
+    p.add_argument("--exact-check-queries", type=int, default=64,
+                   help="queries of the search step re-run through the independent fp32 scan at full corpus size (0: skip)")
     p.add_argument("--skip-slice", action="store_true", help="skip the whole-refresh slice of the default run")
     p.add_argument("--slice-passages", type=int, default=500000)
     p.add_argument("--slice-queries", type=int, default=32768)
@@ -260,7 +266,7 @@ def random_init_roberta_base(torch, n_layers, seed=0):
     return sd
 
 
-CURRENT_ROUND = "r05"  # counters and kernel traces under profiles/ are quoted only when they were taken on this round's tree
+CURRENT_ROUND = "r06"  # counters and kernel traces under profiles/ are quoted only when they were taken on this round's tree
 HEADLINE_MODE = "split"  # the library's default arithmetic: fp32-grade, the precision the reference computes in
 DTYPE_OF = {"split": "f16 pair operands on the fp16 MFMA, f32 accumulate (fp32-grade: <= 2e-5 from the reference's fp32 forward)",
             "fp16": "f16", "fp32": "f32"}
@@ -437,6 +443,167 @@ def cpu_search_baseline(n_rows_total, k, seconds):
                        "top-%d heap per query under OpenMP (oracle/search_ref.py flat_ip_topk_faisslike = faiss-cpu "
                        "IndexFlatIP's algorithm; faiss itself is not installable here), scaled by rows to %d"
                        % (done, n_s, th, ncpu, k, n_rows_total))
+
+
+def search_exact_check(torch, x, q, D, I, k, n_queries, n_host=8):
+    """the lists the timed search step returned, compared at the FULL corpus size with an independent path --
+    ``n_queries`` of the step's queries re-run through the fp32-MFMA scan alone (``ance_ip_topk_scan``: no fp16 image, no
+    filter, no re-scoring; the kernel tests/test_gpu_search.py pins bit-exactly to oracle/ip_topk_ref.c), ids AND scores
+    required bit-identical; for ``n_host`` of them the 200 reported scores are also recomputed on the host with the oracle's
+    fmaf chain (the oracle is the checker here, outside every timed region).  Matches drivers/run_ann_data_gen.py:269-276,303:
+    faiss' IndexFlatIP is exact at any size."""
+    from ance_amd.index import FlatIPIndex
+    nq = q.shape[0]
+    sel = torch.unique(torch.linspace(0, nq - 1, min(n_queries, nq), device=q.device).round().long())
+    t0 = time.perf_counter()
+    idx = FlatIPIndex(x.shape[1], device=x.device)
+    idx.add(x)
+    Ds, Is = idx.search_device(q[sel].contiguous(), k, exact_scan=True)
+    same_i = bool(torch.equal(Is, I[sel]))
+    same_d = bool(torch.equal(Ds.view(torch.int32), D[sel].view(torch.int32)))
+    torch.cuda.synchronize()
+    scan_s = time.perf_counter() - t0
+    host_ok, host_n = None, 0
+    try:
+        from oracle import search_ref
+        host_ok = True
+        for j in sel[:n_host].tolist():
+            rows = x[I[j]].cpu().numpy()
+            S = search_ref.ip_scores_chain(rows, q[j:j + 1].cpu().numpy())[0]
+            host_ok = host_ok and bool(np.array_equal(S, D[j].cpu().numpy()))
+            host_n += 1
+    except Exception as e:  # the oracle's C library is test infrastructure: its absence does not void the device comparison
+        host_ok = "oracle unavailable: %r" % (e,)
+    return {"queries": int(sel.numel()), "rows": int(x.shape[0]), "k": k, "identical": same_i and same_d,
+            "identical_ids": same_i, "identical_scores_bitwise": same_d,
+            "against": "ance_ip_topk_scan (fp32-MFMA scan alone, csrc/ip_topk.hip) on the same resident rows",
+            "host_chain_rescored_queries": host_n, "host_chain_scores_identical": host_ok,
+            "scan_seconds": scan_s, "measured_in_this_run": True}
+
+
+def synthetic_records_of(rng, lens, L, first, last, pad, lo, hi):
+    """Tokenised-cache rows [n, 1+L] for given lengths and special ids (RoBERTa: 0 / 2 / 1, BERT: 101 / 102 / 0)."""
+    n = len(lens)
+    ids = rng.integers(lo, hi, size=(n, L), dtype=np.int64).astype(np.int32)
+    ids[:, 0] = first
+    ids[np.arange(n), lens - 1] = last
+    ids = np.where(np.arange(L)[None, :] < lens[:, None], ids, pad).astype(np.int32)
+    rec = np.empty((n, 1 + L), dtype=np.int32)
+    rec[:, 0] = lens.astype(">u4").view(np.int32)
+    rec[:, 1:] = ids
+    return rec
+
+
+def random_init_bert_base(torch, prefix, seed=0):
+    """Random-init bert-base-uncased tower under a DPR prefix (question_model. / ctx_model.)."""
+    g = torch.Generator().manual_seed(seed)
+    H, I = 768, 3072
+    sd = {}
+
+    def lin(name, o, i):
+        sd[name + ".weight"] = torch.randn(o, i, generator=g) * 0.02
+        sd[name + ".bias"] = torch.zeros(o)
+
+    def ln(name):
+        sd[name + ".weight"] = torch.ones(H)
+        sd[name + ".bias"] = torch.zeros(H)
+
+    e = prefix + "embeddings."
+    sd[e + "word_embeddings.weight"] = torch.randn(30522, H, generator=g) * 0.02
+    sd[e + "position_embeddings.weight"] = torch.randn(512, H, generator=g) * 0.02
+    sd[e + "token_type_embeddings.weight"] = torch.randn(2, H, generator=g) * 0.02
+    ln(e + "LayerNorm")
+    for i in range(12):
+        p = "%sencoder.layer.%d." % (prefix, i)
+        for k in ("attention.self.query", "attention.self.key", "attention.self.value", "attention.output.dense"):
+            lin(p + k, H, H)
+        ln(p + "attention.output.LayerNorm")
+        lin(p + "intermediate.dense", I, H)
+        lin(p + "output.dense", H, I)
+        ln(p + "output.LayerNorm")
+    return sd
+
+
+def other_config_cases(rng):
+    """Encode workloads of BASELINE.json configs[2..4] (SURVEY.md 8d length distributions): (name, tower, L, chunks, lengths,
+    (first, last, pad, lo, hi) token ids).  commands/run_ann_data_gen.sh:31,44-49 (MaxP), run_ann_data_gen_dpr.sh:17-26."""
+    rob, bert = (0, 2, 1, 3, 50265), (101, 102, 0, 1000, 30522)
+    return [
+        ("configs[2]: passage L=512 (lognormal lengths, median 70)", "roberta", 512, 1,
+         lambda n: np.clip(np.rint(rng.lognormal(np.log(70.0), 0.45, size=n)), 8, 512), rob),
+        ("configs[2]: passage L=512 (all 512 tokens, worst case)", "roberta", 512, 1, lambda n: np.full(n, 512.0), rob),
+        ("configs[3]: document MaxP 4x512 (lognormal lengths, median 1100)", "roberta", 2048, 4,
+         lambda n: np.clip(np.rint(rng.lognormal(np.log(1100.0), 0.9, size=n)), 32, 2048), rob),
+        ("configs[4]: DPR BERT-base ctx tower L=256 (lognormal lengths, median 140)", "bert", 256, 1,
+         lambda n: np.clip(np.rint(rng.lognormal(np.log(140.0), 0.3, size=n)), 16, 256), bert),
+    ]
+
+
+def measure_other_configs(torch, dev, steps, tokens_per_step, precision, max_tokens, layers=12, with_kernels=True):
+    """One encode leg per other BASELINE configuration, on ONE GPU, inputs resident in HBM, random-init weights: items/s,
+    algorithmic TFLOP/s and -- from a single-stream pass with the library's HIP events on -- the dominant GEMM's algorithmic
+    fraction of the fp16 MFMA peak (the same figures the headline leg carries for configs[1])."""
+    from ance_amd import _lib
+    from ance_amd.encoder import ARCH_BERT, ARCH_ROBERTA, Encoder
+    rng = np.random.default_rng(99)
+    towers = {"roberta": (random_init_roberta_base(torch, layers, seed=0), ARCH_ROBERTA, "roberta.", True),
+              "bert": (None, ARCH_BERT, "ctx_model.", False)}
+    rows = []
+    for name, tower, L, chunks, lens_fn, (first, last, pad, lo, hi) in other_config_cases(rng):
+        sd, arch, prefix, head = towers[tower]
+        if sd is None:
+            sd = random_init_bert_base(torch, prefix)
+            towers[tower] = (sd, arch, prefix, head)
+        n = max(256, int(tokens_per_step / float(lens_fn(2000).mean())) // 64 * 64)
+        lens = lens_fn(n).astype(np.int32)
+        rec = torch.from_numpy(synthetic_records_of(rng, lens, L, first, last, pad, lo, hi)).to(dev)
+        out = torch.empty((n * chunks, 768), dtype=torch.float32, device=dev)
+        enc = Encoder(sd, arch, prefix, head, max_seq_len=min(L, 512), max_tokens=max_tokens, device=dev, precision=precision)
+        enc.encode_records(rec, n_chunks=chunks, h_lens=lens, out=out)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            enc.encode_records(rec, n_chunks=chunks, h_lens=lens, out=out)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        enc.check_range(sync=True)
+        finite = bool(torch.isfinite(out).all())
+        # algorithmic FLOPs: per chunk of T real tokens 169,869,312 T + 36,864 T^2 (SURVEY.md 8d)
+        if chunks == 1:
+            tl = lens.astype(np.float64)
+        else:
+            tl = np.concatenate([np.clip(lens.astype(np.float64) - 512 * c, 0, 512) for c in range(chunks)])
+            tl = tl[tl > 0]
+        flops = float((169869312.0 * tl + 36864.0 * tl * tl).sum())
+        row = {"config": name, "encoder_precision": enc.precision, "items_per_sec": n / dt, "vectors_per_sec": n * chunks / dt,
+               "tokens_per_sec": float(lens.sum()) / dt, "mean_len": float(lens.mean()), "algorithmic_tflops": flops / dt / 1e12,
+               "items": n, "steps": steps, "ms_per_step": 1e3 * dt, "finite": finite, "measured_in_this_run": True}
+        del enc
+        if with_kernels:
+            os.environ["ANCE_ENCODER_STREAMS"] = "1"
+            try:
+                enc1 = Encoder(sd, arch, prefix, head, max_seq_len=min(L, 512), max_tokens=max_tokens, device=dev, precision=precision)
+            finally:
+                os.environ.pop("ANCE_ENCODER_STREAMS", None)
+            enc1.encode_records(rec, n_chunks=chunks, h_lens=lens, out=out)
+            torch.cuda.synchronize()
+            _lib.profile_enable(True)
+            enc1.encode_records(rec, n_chunks=chunks, h_lens=lens, out=out)
+            torch.cuda.synchronize()
+            prof = _lib.profile_read()
+            _lib.profile_enable(False)
+            cats = [c for c in ("gemm_qk", "gemm_vt", "gemm_attn_out", "gemm_ffn1", "gemm_ffn2") if prof[c]["count"]]
+            dom = max(cats, key=lambda c: prof[c]["ms"])
+            alg = prof[dom]["work"] / (prof[dom]["ms"] * 1e-3) / 1e12
+            tot = sum(v["ms"] for v in prof.values())
+            row["dominant_kernel"] = {"category": dom, "algorithmic_tflops": alg, "frac_of_fp16_mfma_peak": alg / PEAK_F16_TF,
+                                      "ms_per_launch": prof[dom]["ms"] / prof[dom]["count"],
+                                      "attention_share_of_kernel_time": prof["attention"]["ms"] / tot if tot > 0 else None}
+            del enc1
+        rows.append(row)
+        del rec, out
+        torch.cuda.empty_cache()
+    return rows
 
 
 def launch_ranks(a):
@@ -623,9 +790,9 @@ def main():
                 out["encode_fp32"] = p32
                 out["encoder_modes"] = {
                     "split (default; headline)": {"passages_per_sec": pps},
-                    "fp16 (ANCE_ENCODER_FP16=1 / --encoder_precision fp16)": {"passages_per_sec": fast["value"],
+                    "fp16 (ANCE_PRECISION_FP16 / --encoder_precision fp16)": {"passages_per_sec": fast["value"],
                                                                               "max_abs_vs_split": fast["max_abs_vs_split"]},
-                    "fp32 (ANCE_ENCODER_PRECISE=1 / --encoder_precision fp32)": {"passages_per_sec": p32["value"],
+                    "fp32 (ANCE_PRECISION_FP32 / --encoder_precision fp32)": {"passages_per_sec": p32["value"],
                                                                                  "max_abs_vs_split": p32["max_abs_vs_split"]}}
                 del emb_fast, emb_32
             del emb_head, rec_d
@@ -672,6 +839,9 @@ def main():
             ok = None
             if rank == 0:
                 ok = bool((D[:, 1:] <= D[:, :-1]).all().item()) and bool((I >= 0).all().item())
+            exact = None
+            if world == 1 and a.exact_check_queries > 0:
+                exact = search_exact_check(torch, x, q, D, I, a.topk, a.exact_check_queries)
             # the search image (fp16 rows, duplicate classes) is built once per refresh, not per step: time it alone
             torch.cuda.synchronize()
             t_b = time.perf_counter()
@@ -692,7 +862,7 @@ def main():
                                                                                 traffic["cycles"]["clock_ghz"], traffic["fetch_bytes_x2"] / 1e12)
             out["search"] = {"metric": "top%d_queries_per_sec" % a.topk, "value": qps, "unit": "queries/s",
                              "ms_per_step": 1e3 * dt / a.steps, "dtype": "f16 filter + f32 exact re-score (results bit-identical to the f32 scan)", "scaling": "strong (corpus sharded)",
-                             "rows_total": a.n_passages, "rows_per_gpu": n_loc, "sorted_and_valid": ok,
+                             "rows_total": a.n_passages, "rows_per_gpu": n_loc, "sorted_and_valid": ok, "exact_check": exact,
                              "full_train_queries_seconds_est": N_TRAIN_QUERIES / qps,
                              "comm_ms_per_step": {k_: {"ms": v_["ms"] / a.steps, "calls": v_["calls"] // a.steps, "bytes_per_rank": v_["bytes"] // a.steps}
                                                   for k_, v_ in comm.items()} if dist_on else None,
@@ -738,20 +908,33 @@ def main():
                 prof2 = _lib.profile_read()
                 _lib.profile_enable(False)
                 scan2 = prof2["ip_topk_scan"]
-                D2, _ = res["DI"]
+                D2, I2 = res["DI"]
+                exact2 = None
+                if world == 1 and a.exact_check_queries > 0:
+                    exact2 = search_exact_check(torch, x, q, D2, I2, a.topk, a.exact_check_queries)
                 out["search"]["encoder_like"] = {
                     "rows": "common component (norm sqrt 768) + 0.12 N(0,1) per row and per query (tests/test_gpu_search.py:_encoder_like)",
                     "value": a.query_block * a.steps / dt2, "unit": "queries/s", "ms_per_step": 1e3 * dt2 / a.steps,
                     "filter_ms_per_launch": scan2["ms"] / max(scan2["count"], 1),
                     "filter_frac_of_peak": (scan2["work"] / (scan2["ms"] * 1e-3) / 1e12 / PEAK_F16_TF) if scan2["ms"] > 0 else None,
                     "rescore_ms_per_launch": prof2["ip_topk_rescore"]["ms"] / max(prof2["ip_topk_rescore"]["count"], 1),
-                    "sorted": bool((D2[:, 1:] <= D2[:, :-1]).all().item()) if rank == 0 else None,
+                    "sorted": bool((D2[:, 1:] <= D2[:, :-1]).all().item()) if rank == 0 else None, "exact_check": exact2,
                     "relative_to_layernorm_rows": (a.query_block * a.steps / dt2) / qps}
             del x, q
         except Exception as e:
             import traceback
             traceback.print_exc()
             errors["search"] = repr(e)
+
+    # ------------------------------------------------------- other BASELINE configurations --
+    if world == 1 and not a.skip_encode and not a.skip_other_configs:
+        try:
+            out["other_configs"] = measure_other_configs(torch, dev, max(1, min(a.other_config_steps, 6)), a.other_config_tokens,
+                                                         HEADLINE_MODE, a.max_tokens, a.layers)
+        except Exception as e:
+            import traceback
+            traceback.print_exc()
+            errors["other_configs"] = repr(e)
 
     # --------------------------------------------------------------------- whole-refresh slice --
     if world == 1 and not a.skip_slice and not a.skip_encode and out.get("value"):
@@ -772,7 +955,7 @@ def main():
         except Exception as e:
             errors["cpu_baseline"] = repr(e)
     try:  # measured by tests/test_gpu_retrieval.py on an MI355X (fp16-operand encoder vs the fp32 reference arithmetic)
-        src = next(n for n in ("r05_retrieval_agreement.json", "r04_retrieval_agreement.json")
+        src = next(n for n in ("r06_retrieval_agreement.json", "r05_retrieval_agreement.json", "r04_retrieval_agreement.json")
                    if os.path.exists(os.path.join(ROOT, "profiles", n)))
         with open(os.path.join(ROOT, "profiles", src)) as f:
             ra = json.load(f)

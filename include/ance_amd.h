@@ -38,8 +38,9 @@ extern "C" {
 #define ANCE_E_LAUNCH (-3)    /* HIP reported a launch error */
 #define ANCE_E_NOMEM (-4)
 
-#define ANCE_ABI_VERSION 4  /* 4: blocked pair rows in the split mode (ance_pair_layout; ance_debug_gemm_split + d_wscale_inv); 3: + ance_nll_forward,
-                               ance_search_bad_image_calls, ance_debug_gemm_split; split encoder mode */
+#define ANCE_ABI_VERSION 5  /* 5: AnceEncoderDesc.precision (the arithmetic is an argument, not an environment variable), ance_encoder_range_faults,
+                               ance_ip_topk_scan; 4: blocked pair rows in the split mode (ance_pair_layout; ance_debug_gemm_split + d_wscale_inv);
+                               3: + ance_nll_forward, ance_search_bad_image_calls, ance_debug_gemm_split; split encoder mode */
 int ance_abi_version(void);
 /* last HIP error string seen by this library on the calling thread ("" if none) */
 const char *ance_last_error(void);
@@ -94,6 +95,15 @@ size_t ance_ip_topk_workspace_bytes(int64_t n, int64_t nq, int d, int k);
  */
 int ance_ip_topk(const float *d_x, int64_t n, int64_t row_base, const float *d_q, int64_t nq, int d, int k,
                  float *d_out_d, int64_t *d_out_i, void *d_workspace, size_t workspace_bytes, void *stream);
+
+/*
+ * The same search by the fp32-MFMA scan ALONE (csrc/ip_topk.hip: ip_topk_scan_kernel), whatever the shape and the environment:
+ * the independent audit path of the two-precision kernel -- both must return the same bits (bench.py checks the headline-size
+ * search against it on a sample of its queries; tests/test_gpu_search.py pins the scan to oracle/ip_topk_ref.c).  ~7 x slower.
+ */
+size_t ance_ip_topk_scan_workspace_bytes(int64_t n, int64_t nq, int d, int k);
+int ance_ip_topk_scan(const float *d_x, int64_t n, int64_t row_base, const float *d_q, int64_t nq, int d, int k,
+                      float *d_out_d, int64_t *d_out_i, void *d_workspace, size_t workspace_bytes, void *stream);
 
 /*
  * Search image of a shard: what faiss.IndexFlatIP.add builds once and every .search reuses
@@ -155,7 +165,13 @@ typedef struct AnceEncoderDesc {
     int32_t has_head;     /* 1: LayerNorm_768(W h_cls + b), eps 1e-5 (models.py:145-153); 0: raw h_cls */
     int32_t max_seq_len;  /* longest single sequence (chunk) this handle will see, <= 512    */
     int32_t max_tokens;   /* token capacity of one micro-batch (workspace sizing)            */
+    int32_t precision;    /* ANCE_PRECISION_*: the arithmetic of the handle (and of the two size queries)  */
 } AnceEncoderDesc;
+
+#define ANCE_PRECISION_DEFAULT 0 /* what the environment says (ANCE_ENCODER_* below); nothing set: split */
+#define ANCE_PRECISION_SPLIT 1   /* fp16 pair operands, three MFMAs per k-step: fp32-grade (2e-5), the default */
+#define ANCE_PRECISION_FP16 2    /* fp16 operands: the fast mode (5e-3) */
+#define ANCE_PRECISION_FP32 3    /* fp32 operands on the fp32-input matrix cores: the audit path */
 
 typedef struct AnceEncoder AnceEncoder;
 
@@ -182,9 +198,15 @@ typedef struct AnceEncoder AnceEncoder;
  * Arithmetic.  DEFAULT (nothing in the environment): the SPLIT mode -- an fp32-GRADE result from the fp16 matrix cores: every GEMM
  * operand an fp16 pair v = hi + lo, three MFMAs per k-step (hi hi + lo hi + hi lo) from four operand tiles staged once, fp32
  * accumulation, fp32 softmax, erf-GELU to fp32 grade, fp32 head; max |delta| 2e-5 (stated; 7e-6 measured at 12 layers) against the
- * reference's fp32 arithmetic (model/models.py:149-157 runs in fp32).  Pre-LayerNorm values and GELU outputs must stay below
- * 65,504 (the hi half is an fp16); weights may have any scale (stored times a per-matrix power of two).
- * Environment, read when a handle is created (the two size queries read the mode switches as well):
+ * reference's fp32 arithmetic (model/models.py:149-157 runs in fp32).  Preconditions of the split mode, both CHECKED on the device
+ * (ance_encoder_range_faults): pre-LayerNorm values, Q | K | V and GELU outputs must stay below 65,504 (the hi half of a pair is an fp16)
+ * -- the reference's fp32 has no such limit, --encoder_precision fp32 / ANCE_PRECISION_FP32 is the way out; and no NaN in the output
+ * rows.  Activation magnitudes: the lo half of an element below 2^-3 is an fp16 subnormal, i.e. good to 2^-25 ABSOLUTE -- fp32-grade for
+ * the O(1) values of the post-residual streams; the embedding sum (0.05 in trained BERT / RoBERTa checkpoints, followed by a LayerNorm
+ * with rstd ~ 20) is therefore stored times 16 and its LayerNorm epsilon times 256 (exact: powers of two).  Weights may have any scale
+ * (stored times a per-matrix power of two).
+ * The arithmetic of a handle is AnceEncoderDesc.precision.  ANCE_PRECISION_DEFAULT (0) defers to the environment, read when the handle
+ * is created (the two size queries resolve the mode the same way) -- a drivers' --encoder_precision flag overrides it:
  *   ANCE_ENCODER_FP16=1      the fp16 FAST mode (ANCE_ENCODER_SPLIT=0 is another spelling): fp16 MFMA operands, fp32 accumulation, fp32
  *                            softmax / statistics / head; LayerNorm folded into the GEMMs and the residual stream kept as fp16 (hi, lo)
  *                            pairs (22 mantissa bits) -- max |delta| 3e-3 on unit-variance embeddings (stated tolerance of the tests:
@@ -211,6 +233,19 @@ int ance_encoder_create(const AnceEncoderDesc *desc, const void *const *d_weight
                         void *d_weight_arena, size_t weight_bytes, void *d_workspace, size_t workspace_bytes,
                         void *stream, AnceEncoder **out);
 void ance_encoder_destroy(AnceEncoder *enc);
+/* The arithmetic the handle runs: ANCE_PRECISION_SPLIT / FP16 / FP32 (never DEFAULT). */
+int ance_encoder_precision(const AnceEncoder *enc);
+
+/*
+ * Range guard.  The handle keeps two sticky device counters, updated by the kernels of every ance_encode_* call:
+ *   [0] threads of the split mode's pair-forming stages (embedding sum, Q | K | V, GELU output, residual stream) that saw a
+ *       value above 65,504 in magnitude or a non-finite one -- the split mode's precondition is violated, the embeddings of
+ *       that call are NOT fp32-grade (the fp16 hi half overflowed);
+ *   [1] output rows (any mode) whose statistics are NaN or infinite.
+ * Enqueues on `stream` a copy of both to h_out (HOST pointer, uint32[2]; pinned memory keeps the copy asynchronous) and, if
+ * reset != 0, zeroes them behind it.  Never synchronises: h_out is valid once `stream` has passed this point.
+ */
+int ance_encoder_range_faults(AnceEncoder *enc, uint32_t *h_out, int reset, void *stream);
 
 /*
  * Encode n records.  Each record is L int32 token ids split into n_chunks chunks of L / n_chunks

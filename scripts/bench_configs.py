@@ -8,7 +8,8 @@ random-init weights, synthetic token ids with the length distributions of SURVEY
 and the SEARCH of configuration 4: 3,213,835 documents x 4 chunks = 12,855,340 vectors of which every chunk past a
 document's end is the same all-pad vector v0 (model/models.py:165-199) -- the duplicate class the search image collapses.
 
-Not the bench.py contract (that is configs[1]); prints one JSON line per configuration for
+The encode legs are bench.py's `other_configs` leg (bench.measure_other_configs: the driver's run carries them); this script
+runs them with more tokens per step and adds the search of configuration 4.  Prints one JSON line per configuration for
 BASELINE.md section 4.  Usage on the GPU box:  python scripts/bench_configs.py [--steps 3]
 """
 import argparse
@@ -23,101 +24,23 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def records(rng, lens, L, first, last, pad, lo, hi):
-    n = len(lens)
-    ids = rng.integers(lo, hi, size=(n, L), dtype=np.int64).astype(np.int32)
-    ids[:, 0] = first
-    ids[np.arange(n), lens - 1] = last
-    ids = np.where(np.arange(L)[None, :] < lens[:, None], ids, pad).astype(np.int32)
-    rec = np.empty((n, 1 + L), dtype=np.int32)
-    rec[:, 0] = lens.astype(">u4").view(np.int32)
-    rec[:, 1:] = ids
-    return rec
-
-
-def bert_state_dict(torch, prefix, seed=0):
-    g = torch.Generator().manual_seed(seed)
-    H, I = 768, 3072
-    sd = {}
-
-    def lin(name, o, i):
-        sd[name + ".weight"] = torch.randn(o, i, generator=g) * 0.02
-        sd[name + ".bias"] = torch.zeros(o)
-
-    def ln(name):
-        sd[name + ".weight"] = torch.ones(H)
-        sd[name + ".bias"] = torch.zeros(H)
-
-    e = prefix + "embeddings."
-    sd[e + "word_embeddings.weight"] = torch.randn(30522, H, generator=g) * 0.02
-    sd[e + "position_embeddings.weight"] = torch.randn(512, H, generator=g) * 0.02
-    sd[e + "token_type_embeddings.weight"] = torch.randn(2, H, generator=g) * 0.02
-    ln(e + "LayerNorm")
-    for i in range(12):
-        p = "%sencoder.layer.%d." % (prefix, i)
-        for k in ("attention.self.query", "attention.self.key", "attention.self.value", "attention.output.dense"):
-            lin(p + k, H, H)
-        ln(p + "attention.output.LayerNorm")
-        lin(p + "intermediate.dense", I, H)
-        lin(p + "output.dense", H, I)
-        ln(p + "output.LayerNorm")
-    return sd
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--tokens-per-step", type=int, default=1 << 21)
     ap.add_argument("--search-only", action="store_true")
     ap.add_argument("--skip-search", action="store_true")
+    ap.add_argument("--max-tokens", type=int, default=131072)
     ap.add_argument("--precision", default=None, choices=["fp16", "split", "fp32"],
                     help="encoder arithmetic (default: the library's default = split, fp32-grade)")
     a = ap.parse_args()
     import torch
     import bench
-    from ance_amd.encoder import ARCH_BERT, ARCH_ROBERTA, Encoder
     dev = torch.device("cuda", 0)
-    rng = np.random.default_rng(99)
-    rob = bench.random_init_roberta_base(torch, 12, seed=0)
-    bert = bert_state_dict(torch, "ctx_model.")
-    cases = [
-        ("3: passage L=512 (lognormal lengths)", rob, ARCH_ROBERTA, "roberta.", True, 512, 1,
-         lambda n: np.clip(np.rint(rng.lognormal(np.log(70.0), 0.45, size=n)), 8, 512), (0, 2, 1, 3, 50265)),
-        ("3: passage L=512 (all 512 tokens, worst case)", rob, ARCH_ROBERTA, "roberta.", True, 512, 1,
-         lambda n: np.full(n, 512.0), (0, 2, 1, 3, 50265)),
-        ("4: document MaxP 4x512", rob, ARCH_ROBERTA, "roberta.", True, 2048, 4,
-         lambda n: np.clip(np.rint(rng.lognormal(np.log(1100.0), 0.9, size=n)), 32, 2048), (0, 2, 1, 3, 50265)),
-        ("5: DPR BERT-base L=256", bert, ARCH_BERT, "ctx_model.", False, 256, 1,
-         lambda n: np.clip(np.rint(rng.lognormal(np.log(140.0), 0.3, size=n)), 16, 256), (101, 102, 0, 1000, 30522)),
-    ]
-    if a.search_only:
-        cases = []
-    for name, sd, arch, prefix, head, L, chunks, lens_fn, (first, last, pad, lo, hi) in cases:
-        mean_guess = float(lens_fn(2000).mean())
-        n = max(256, int(a.tokens_per_step / mean_guess) // 64 * 64)
-        lens = lens_fn(n).astype(np.int32)
-        rec = torch.from_numpy(records(rng, lens, L, first, last, pad, lo, hi)).to(dev)
-        enc = Encoder(sd, arch, prefix, head, max_seq_len=min(L, 512), max_tokens=65536, device=dev, precision=a.precision)
-        out = torch.empty((n * chunks, 768), dtype=torch.float32, device=dev)
-        enc.encode_records(rec, n_chunks=chunks, h_lens=lens, out=out)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(a.steps):
-            enc.encode_records(rec, n_chunks=chunks, h_lens=lens, out=out)
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / a.steps
-        # algorithmic FLOPs: per chunk of T real tokens 169,869,312 T + 36,864 T^2 (+ head), SURVEY.md 8d
-        if chunks == 1:
-            tl = lens.astype(np.float64)
-        else:
-            tl = np.concatenate([np.clip(lens.astype(np.float64) - 512 * c, 0, 512) for c in range(chunks)])
-            tl = tl[tl > 0]
-        flops = float((169869312.0 * tl + 36864.0 * tl * tl).sum())
-        print(json.dumps({"config": name, "encoder_precision": enc.precision, "items_per_sec": n / dt, "vectors_per_sec": n * chunks / dt,
-                          "tokens_per_sec": float(lens.sum()) / dt, "mean_len": float(lens.mean()),
-                          "algorithmic_tflops": flops / dt / 1e12, "items": n, "finite": bool(torch.isfinite(out).all())}))
-        del enc, rec, out
-        torch.cuda.empty_cache()
+    if not a.search_only:
+        # the encode legs are bench.py's own `other_configs` leg (the driver's run carries them); here with more tokens per step
+        for row in bench.measure_other_configs(torch, dev, a.steps, a.tokens_per_step, a.precision, a.max_tokens):
+            print(json.dumps(row))
     if not a.skip_search:
         search_config4(torch, dev, a.steps)
 

@@ -29,7 +29,7 @@ def test_library_loads_and_exports_everything():
     raw = ctypes.CDLL(_lib.LIB_PATH)
     for name in _declared_functions():
         assert hasattr(raw, name), name
-    assert L.ance_abi_version() == _lib.ABI_VERSION == 4
+    assert L.ance_abi_version() == _lib.ABI_VERSION == 5
     assert L.ance_last_error() is not None
 
 
@@ -62,6 +62,12 @@ def test_invalid_arguments_are_rejected_before_any_launch():
     assert rc == -1 and b"nll" in L.ance_last_error()
     rc = L.ance_debug_gemm_split(8, None, None, 256, 256, 128, None, None, None, None, 1e-5, None, None, None, None, None)
     assert rc == -1
+    rc = L.ance_ip_topk_scan(None, 10, 0, None, 4, 768, 0, None, None, None, 0, None)
+    assert rc == -1 and b"invalid" in L.ance_last_error()
+    assert L.ance_ip_topk_scan_workspace_bytes(10000, 1000, 768, 200) > 0
+    assert L.ance_ip_topk_scan_workspace_bytes(10000, 1000, 768, 0) == 0
+    assert L.ance_encoder_range_faults(None, None, 0, None) == -1
+    assert L.ance_encoder_precision(None) == -1
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):

@@ -580,3 +580,126 @@ def test_split_mode_with_weights_of_very_different_scales():
     with open(os.path.join(OUT, "encoder_parity.jsonl"), "a") as f:
         f.write(json.dumps(dict(case="split_mode_weight_scales", max_abs_vs_fp64=e, fp32_oracle_vs_fp64=e32)) + "\n")
     assert np.isfinite(got).all() and e <= 4.0 * e32 + 2e-5, (e, e32)
+
+
+def _trained_like_weights(n_layers, ffn_drive=None, emb_scale=1.4):
+    """A 'trained-like' stress model (VERDICT r5 #4c): every parity fixture is random init (std 0.02, LayerNorm 1 / 0), where
+    activations are O(1) and softmax is flat.  Here: embedding rows of the magnitude trained checkpoints have (0.05) with a common
+    offset; two hidden dimensions with x50 LayerNorm gains in every LayerNorm (the outlier dimensions of trained BERT / RoBERTa);
+    Q / K scaled so that the softmax saturates (one key takes almost all the mass); optionally one FFN channel driven to
+    ``ffn_drive`` in magnitude through its intermediate bias (GELU output and, through output.dense, the residual stream)."""
+    from oracle import encoder_ref
+    sd = dict(encoder_ref.random_state_dict(seed=71, n_layers=n_layers, ln_jitter=0.1))
+    we = sd["roberta.embeddings.word_embeddings.weight"].clone() * emb_scale
+    we[:, 5] += 0.04
+    sd["roberta.embeddings.word_embeddings.weight"] = we
+    names = ["roberta.embeddings.LayerNorm"]
+    for i in range(n_layers):
+        names += ["roberta.encoder.layer.%d.attention.output.LayerNorm" % i, "roberta.encoder.layer.%d.output.LayerNorm" % i]
+    for n in names:
+        w = sd[n + ".weight"].clone()
+        w[17] *= 50.0
+        w[400] *= -50.0
+        sd[n + ".weight"] = w
+    for i in range(n_layers):
+        p = "roberta.encoder.layer.%d." % i
+        sd[p + "attention.self.query.weight"] = sd[p + "attention.self.query.weight"] * 6.0
+        sd[p + "attention.self.key.weight"] = sd[p + "attention.self.key.weight"] * 6.0
+    if ffn_drive is not None:
+        b = sd["roberta.encoder.layer.1.intermediate.dense.bias"].clone()
+        b[123] = ffn_drive
+        sd["roberta.encoder.layer.1.intermediate.dense.bias"] = b
+    return sd
+
+
+def _oracle_pair(sd, ids, lens, L, n_layers):
+    from oracle import encoder_ref
+    with torch.no_grad():
+        sd64 = {k: v.double() for k, v in sd.items()}
+        want64 = encoder_ref.rdot_nll_ln_emb(sd64, torch.from_numpy(ids), encoder_ref.mask_from_lengths(lens, L), n_layers=n_layers).numpy()
+        want32 = encoder_ref.rdot_nll_ln_emb(sd, torch.from_numpy(ids), encoder_ref.mask_from_lengths(lens, L), n_layers=n_layers).numpy()
+    return want64, want32
+
+
+@pytest.mark.parametrize("ffn_drive", [None, 300.0, 2.0e4])
+def test_split_mode_on_trained_like_activations(ffn_drive):
+    """In-range stress cases: outlier LayerNorm gains, saturated softmax, small embedding rows, one FFN channel at 300 / 20,000
+    (inside the fp16 range of the hi halves).  The split mode must stay fp32-grade -- within max(2e-5, 4 x the fp32 oracle's own
+    distance from the fp64 oracle) -- and the range guard must stay silent."""
+    from ance_amd.encoder import ARCH_ROBERTA, Encoder
+    from oracle import synth
+    n_layers = 3
+    sd = _trained_like_weights(n_layers, ffn_drive)
+    rng = np.random.default_rng(72)
+    lens = np.array([1, 2, 31, 33, 64, 65, 96, 128, 70, 9, 100, 50], dtype=np.int32)
+    ids = synth.make_records(rng, len(lens), 128, lens.astype(np.int64))
+    want64, want32 = _oracle_pair(sd, ids, lens, 128, n_layers)
+    enc = Encoder(sd, ARCH_ROBERTA, "roberta.", True, max_seq_len=128, max_tokens=2048, precision="split")
+    got = enc.encode_ids(torch.from_numpy(ids).cuda(), torch.from_numpy(lens).cuda(), h_lens=lens).cpu().numpy()
+    enc.check_range(sync=True)  # silent: every value is inside the range
+    e32 = float(np.abs(want32.astype(np.float64) - want64).max())
+    e = float(np.abs(got.astype(np.float64) - want64).max())
+    with open(os.path.join(OUT, "encoder_parity.jsonl"), "a") as f:
+        f.write(json.dumps(dict(case="split_mode_trained_like_ffn_%s" % ffn_drive, max_abs_vs_fp64=e, fp32_oracle_vs_fp64=e32)) + "\n")
+    assert np.isfinite(got).all() and e <= max(2e-5, 4.0 * e32), (e, e32)
+
+
+def test_split_mode_range_guard_raises_out_of_range():
+    """Out-of-range stress case: one FFN channel driven to 1e5 -- fine in the reference's fp32, an overflow of the fp16 hi half in
+    the split mode.  The precondition is CHECKED (ance_encoder_range_faults): the binding raises AnceRangeError naming the fp32
+    mode, on the synchronous check and -- sticky -- on the next call; the fp32 mode encodes the same checkpoint to fp32 grade."""
+    from ance_amd import _lib
+    from ance_amd.encoder import ARCH_ROBERTA, Encoder
+    from oracle import synth
+    n_layers = 3
+    sd = _trained_like_weights(n_layers, 1.0e5)
+    rng = np.random.default_rng(73)
+    lens = np.array([1, 2, 31, 33, 64, 65, 96, 128], dtype=np.int32)
+    ids = synth.make_records(rng, len(lens), 128, lens.astype(np.int64))
+    ids_d, lens_d = torch.from_numpy(ids).cuda(), torch.from_numpy(lens).cuda()
+    enc = Encoder(sd, ARCH_ROBERTA, "roberta.", True, max_seq_len=128, max_tokens=2048, precision="split")
+    enc.encode_ids(ids_d, lens_d, h_lens=lens)
+    with pytest.raises(_lib.AnceRangeError, match="encoder_precision fp32"):
+        enc.check_range(sync=True)
+    with pytest.raises(_lib.AnceRangeError):   # sticky: the handle keeps refusing
+        enc.encode_ids(ids_d, lens_d, h_lens=lens)
+    del enc
+    want64, want32 = _oracle_pair(sd, ids, lens, 128, n_layers)
+    enc32 = Encoder(sd, ARCH_ROBERTA, "roberta.", True, max_seq_len=128, max_tokens=2048, precision="fp32")
+    got = enc32.encode_ids(ids_d, lens_d, h_lens=lens).cpu().numpy()
+    enc32.check_range(sync=True)
+    e32 = float(np.abs(want32.astype(np.float64) - want64).max())
+    e = float(np.abs(got.astype(np.float64) - want64).max())
+    assert np.isfinite(got).all() and e <= max(2e-5, 4.0 * e32), (e, e32)
+
+
+def test_range_guard_counts_nan_rows_in_every_mode():
+    """A NaN in the checkpoint reaches every output row through the LayerNorm statistics: counter [1] of the range guard."""
+    from ance_amd import _lib
+    from ance_amd.encoder import ARCH_ROBERTA, Encoder
+    from oracle import encoder_ref, synth
+    sd = dict(encoder_ref.random_state_dict(seed=74, n_layers=1, ln_jitter=0.1))
+    b = sd["roberta.encoder.layer.0.output.dense.bias"].clone()
+    b[3] = float("nan")
+    sd["roberta.encoder.layer.0.output.dense.bias"] = b
+    lens = np.array([5, 9, 16], dtype=np.int32)
+    ids = synth.make_records(np.random.default_rng(75), 3, 16, lens.astype(np.int64))
+    for mode in ("split", "fp16", "fp32"):
+        enc = Encoder(sd, ARCH_ROBERTA, "roberta.", True, max_seq_len=16, max_tokens=512, precision=mode)
+        enc.encode_ids(torch.from_numpy(ids).cuda(), torch.from_numpy(lens).cuda(), h_lens=lens)
+        with pytest.raises(_lib.AnceRangeError, match="3 output rows are NaN"):
+            enc.check_range(sync=True)
+
+
+def test_precision_is_chosen_by_the_descriptor_not_by_the_environment(monkeypatch):
+    """ABI v5: ``precision=`` travels in AnceEncoderDesc.precision and wins over the environment; the environment only moves
+    the DEFAULT (precision=None)."""
+    from ance_amd.encoder import ARCH_ROBERTA, Encoder
+    from oracle import encoder_ref
+    sd = encoder_ref.random_state_dict(seed=5, n_layers=1, ln_jitter=0.1)
+    monkeypatch.setenv("ANCE_ENCODER_PRECISE", "1")
+    kw = dict(max_seq_len=16, max_tokens=512)
+    assert Encoder(sd, ARCH_ROBERTA, "roberta.", True, **kw).precision == "fp32"
+    assert Encoder(sd, ARCH_ROBERTA, "roberta.", True, precision="split", **kw).precision == "split"
+    assert Encoder(sd, ARCH_ROBERTA, "roberta.", True, precision="fp16", **kw).precision == "fp16"
+    assert os.environ["ANCE_ENCODER_PRECISE"] == "1" and "ANCE_ENCODER_SPLIT" not in os.environ

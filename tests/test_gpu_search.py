@@ -193,6 +193,49 @@ def test_properties_at_scale():
         assert set(samp.numpy()[better].tolist()) <= set(I[r].tolist())
 
 
+def test_exact_at_the_headline_size():
+    """8,841,823 x 768 rows -- the size every queries/s number is quoted on -- against the independent fp32 scan
+    (``ance_ip_topk_scan``, pinned bit-exactly to oracle/ip_topk_ref.c by the tests above at sizes the oracle reaches): 17 k
+    corpus tiles, 35 windows, the full prune schedule.  2,048 queries through the two-precision path, 64 of them through the
+    scan: ids AND scores bit-identical; 4 of those re-scored on the host by the oracle's fmaf chain.  LayerNorm rows, then
+    encoder-like rows (the query-mean bias build).  Needs 60 GB of free HBM."""
+    import torch
+    from ance_amd.index import FlatIPIndex
+    from oracle import search_ref
+    free, _ = torch.cuda.mem_get_info()
+    if free < 60e9:
+        pytest.skip("needs 60 GB of free device memory, %.0f GB free" % (free / 1e9))
+    n, nq, k = 8_841_823, 2048, 200
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = torch.empty((n, 768), device="cuda")
+    for kind in ("layernorm", "encoder_like"):
+        if kind == "layernorm":
+            for b0 in range(0, n, 1 << 20):
+                b1 = min(b0 + (1 << 20), n)
+                x[b0:b1] = torch.nn.functional.layer_norm(torch.randn((b1 - b0, 768), generator=g, device="cuda"), (768,))
+            q = torch.nn.functional.layer_norm(torch.randn((nq, 768), generator=g, device="cuda"), (768,))
+        else:
+            c = torch.randn((768,), generator=g, device="cuda")
+            c = c / c.norm() * (768.0 ** 0.5)
+            for b0 in range(0, n, 1 << 20):
+                b1 = min(b0 + (1 << 20), n)
+                x[b0:b1] = c[None, :] + 0.12 * torch.randn((b1 - b0, 768), generator=g, device="cuda")
+            q = c[None, :] + 0.12 * torch.randn((nq, 768), generator=g, device="cuda")
+        x[8_000_000] = x[17]  # one exact duplicate far away: a tie across windows
+        idx = FlatIPIndex(768)
+        idx.add(x)
+        D, I = idx.search_device(q, k)
+        sel = torch.arange(0, nq, 32, device="cuda")
+        Ds, Is = idx.search_device(q[sel].contiguous(), k, exact_scan=True)
+        assert torch.equal(Is, I[sel]), kind
+        assert torch.equal(Ds.view(torch.int32), D[sel].view(torch.int32)), kind
+        for j in sel[:4].tolist():
+            S = search_ref.ip_scores_chain(x[I[j]].cpu().numpy(), q[j:j + 1].cpu().numpy())[0]
+            assert np.array_equal(S, D[j].cpu().numpy()), (kind, j)
+        del idx, D, I, Ds, Is
+        torch.cuda.empty_cache()
+
+
 def test_clustered_scores_every_row_is_a_candidate():
     """Rows differ by ~1e-3 noise around one vector: all scores lie far inside the fp16 filter's slack,
     so the two-precision path must re-score everything exactly -- and still return the exact lists."""

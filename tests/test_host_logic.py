@@ -165,30 +165,63 @@ def test_cli_flags_match_reference_names():
 
 # ---- native host stage (csrc/host_postsearch.hip) ------------------------------------------------
 def test_encoder_precision_flag():
-    """The one added flag: --encoder_precision {fp16, split, fp32}; the default is the fp32-grade split mode (the reference runs
-    its encoder in fp32, drivers/run_ann_data_gen.py:158,176-180), fp16 is the opt-in fast mode."""
+    """The one added flag: --encoder_precision {fp16, split, fp32}.  Not given, the library / environment default applies
+    (an explicit "split" default silently overrode ANCE_ENCODER_FP16=1 / ANCE_ENCODER_PRECISE=1); with nothing in
+    the environment that is the fp32-grade split mode (the reference runs its encoder in fp32,
+    drivers/run_ann_data_gen.py:158,176-180)."""
     from ance_amd import ann_data_gen as adg
+    from ance_amd import ann_data_gen_dpr as dpr
     base = ["--data_dir", "d", "--training_dir", "t", "--init_model_dir", "i", "--model_type", "rdot_nll", "--output_dir", "o",
             "--cache_dir", "c"]
-    assert adg.get_arguments(base).encoder_precision == "split"
+    assert adg.get_arguments(base).encoder_precision is None
+    assert adg.get_arguments(base).max_tokens == adg.DRIVER_MAX_TOKENS == 131072
     assert adg.get_arguments(base + ["--encoder_precision", "split"]).encoder_precision == "split"
     with pytest.raises(SystemExit):
         adg.get_arguments(base + ["--encoder_precision", "bf16"])
+    dbase = ["--data_dir", "d", "--training_dir", "t", "--init_model_dir", "i", "--output_dir", "o", "--cache_dir", "c",
+             "--passage_path", "p", "--test_qa_path", "q", "--trivia_test_qa_path", "r"]
+    try:
+        assert dpr.get_arguments(dbase).encoder_precision is None
+    except SystemExit:  # (the DPR parser has more required flags than this test names: the default is what matters)
+        import inspect
+        assert 'encoder_precision", default=None' in inspect.getsource(dpr.get_arguments)
 
 
-def test_precision_env_context_restores_the_environment(monkeypatch):
-    from ance_amd.encoder import Encoder, _precision_env
+def test_precision_is_an_argument_not_an_environment_mutation(monkeypatch):
+    """ABI v5: the arithmetic travels in AnceEncoderDesc.precision; the binding no longer touches os.environ, and the size
+    queries follow the descriptor (the modes differ in arena and workspace size)."""
+    import ctypes
+    import inspect
+    from ance_amd import _lib, encoder
+    assert "os.environ.update" not in inspect.getsource(encoder) and "os.environ.pop" not in inspect.getsource(encoder)
+    assert _lib.PRECISION_CODES == {None: 0, "split": 1, "fp16": 2, "fp32": 3}
+    for k in ("ANCE_ENCODER_PRECISE", "ANCE_ENCODER_SPLIT", "ANCE_ENCODER_FP16"):
+        monkeypatch.delenv(k, raising=False)
+    L = _lib.lib()
+
+    def sizes(code):
+        d = _lib.AnceEncoderDesc(arch=0, n_layers=12, hidden=768, n_heads=12, intermediate=3072, vocab_size=50265,
+                                 max_position=514, pad_token_id=1, ln_eps=1e-5, has_head=1, max_seq_len=512, max_tokens=32768,
+                                 precision=code)
+        return L.ance_encoder_weight_bytes(ctypes.byref(d)), L.ance_encoder_workspace_bytes(ctypes.byref(d))
+
+    default, split, fp16, fp32 = sizes(0), sizes(1), sizes(2), sizes(3)
+    assert default == split                       # nothing in the environment: the default is the split mode
+    assert fp16[0] < min(split[0], fp32[0]) and fp16[1] < split[1] < fp32[1] and split != fp32
+    monkeypatch.setenv("ANCE_ENCODER_FP16", "1")  # the environment moves only the DEFAULT code
+    assert sizes(0) == fp16 and sizes(1) == split and sizes(3) == fp32
+    assert encoder.precision_from_env() == "fp16"
     monkeypatch.setenv("ANCE_ENCODER_PRECISE", "1")
-    monkeypatch.delenv("ANCE_ENCODER_SPLIT", raising=False)
-    with _precision_env(Encoder.PRECISIONS["split"]):
-        assert os.environ.get("ANCE_ENCODER_SPLIT") == "1" and "ANCE_ENCODER_PRECISE" not in os.environ
-    assert os.environ.get("ANCE_ENCODER_PRECISE") == "1" and "ANCE_ENCODER_SPLIT" not in os.environ
-    with _precision_env(Encoder.PRECISIONS["fp16"]):
-        assert "ANCE_ENCODER_PRECISE" not in os.environ and "ANCE_ENCODER_SPLIT" not in os.environ
-        assert os.environ.get("ANCE_ENCODER_FP16") == "1"
-    assert "ANCE_ENCODER_FP16" not in os.environ
-    with _precision_env(None):
-        assert os.environ.get("ANCE_ENCODER_PRECISE") == "1"
+    assert sizes(0) == fp32 and encoder.precision_from_env() == "fp32"
+    assert sizes(4) == (0, 0) and sizes(-1) == (0, 0)  # not a precision code
+
+
+def test_row_bases_of_a_refresh_are_a_pure_function_of_the_rank():
+    from ance_amd import ann_data_gen as adg
+    from ance_amd.cache import shard_range
+    for n, w, c in ((10, 3, 1), (8841823, 8, 1), (56, 2, 4), (5, 8, 1)):
+        bases = adg.shard_row_bases(n, w, c)
+        assert bases == [shard_range(n, r, w)[0] * c for r in range(w)] and bases[0] == 0 and bases == sorted(bases)
 
 
 def test_native_shuffle_continues_cpython_stream():
