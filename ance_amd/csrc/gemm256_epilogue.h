@@ -541,4 +541,139 @@ __device__ __forceinline__ void gemm256_epilogue_split(const GemmArgs &G, f32x16
     range_report(vmax, G.range_faults);
 }
 
+// ---- epilogues of the STREAMING (persistent) split GEMM ------------------------------------------------------------------
+// The same three epilogues, bit for bit (tests/test_gpu_gemm.py compares the two kernels with array_equal), in the LDS the
+// persistent kernel has left while the next output tile's first K-tiles are in flight in the stage buffers: a wave-private slab of
+// [32 m][32 n] fp32 (row stride 36 floats: the 16-byte writes of 16 lanes fall into 16 different bank quads; 4.5 KiB per wave
+// instead of the 16 KiB slices of the stage buffers the launch-per-tile kernel's epilogue reuses), EIGHT passes (y, x) of 32 rows x 32
+// columns.  A 32-column block is exactly one [hi (32) | lo (32)] block of a pair row (common.h): on read-back 8 lanes cover a row
+// -- 128 contiguous bytes of fp32 (EPI_S_QKV) or the 64 + 64 bytes of one pair block -- 8 rows per instruction.
+// EPI_S_RESLN: the residual pair of pass p + 1 is requested before pass p's slab round trip (one pass of latency hidden per pass);
+// the (mean, M2) of a 64-column slice combine the two passes x = 0, 1 of a row block in the association of the 16-lane reduction
+// above (slice64_sum).
+// sum over the 4 lanes of a quad (every lane of the quad ends with the same bits) / the value of lane 7 - j of the 8-lane group
+__device__ __forceinline__ float quad_sum(float x) {
+    x += __builtin_amdgcn_update_dpp(0.f, x, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
+    x += __builtin_amdgcn_update_dpp(0.f, x, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
+    return x;
+}
+__device__ __forceinline__ float half_mirror(float x) { return __builtin_amdgcn_update_dpp(0.f, x, 0x141, 0xF, 0xF, true); }
+// The 64-column reduction of row16_sum from the two 32-column passes of this epilogue, in row16_sum's OWN association: there the
+// four quads of a DPP row hold column blocks Q0..Q3 of 16 columns and after  row_ror:4, row_ror:8  quad k holds
+// (Qk + Qk-1) + (Qk-2 + Qk-3)  -- the lanes of Q0 and Q2 end with (Q0 + Q3) + (Q1 + Q2), those of Q1 and Q3 with (Q0 + Q1) + (Q2 + Q3),
+// and lane 0 (which stores the statistics) is in Q0.  Here pass x = 0 has Q0 on lanes 0-3 and Q1 on lanes 4-7 of an 8-lane group,
+// pass x = 1 has Q2 | Q3: a = the quad sums of pass 0, b = of pass 1.
+__device__ __forceinline__ float slice64_sum(float a, float b, bool low_quad) {
+    const float ma = half_mirror(a), mb = half_mirror(b);
+    const float lo = (a + mb) + (ma + b);   // lanes 0-3: (Q0 + Q3) + (Q1 + Q2)
+    const float hi = (a + ma) + (b + mb);   // lanes 4-7: (Q1 + Q0) + (Q3 + Q2)
+    return low_quad ? lo : hi;
+}
+
+constexpr int EPS_LS = 36;                       // slab row stride (floats)
+constexpr int EPS_SLAB_FLOATS = 32 * EPS_LS;     // 4,608 bytes per wave
+
+template <int EPI>
+__device__ __forceinline__ void gemm256_epilogue_split32(const GemmArgs &G, f32x16 (&acc)[2][4], float *slab, const float *stats,
+                                                         const float *vec, int m0, int n0, int w, int l, float winv) {
+#pragma clang fp contract(off)
+    const int g = l >> 5, i = l & 31;
+    const int wm = w >> 2, wn = w & 3;
+    const int mw0 = m0 + wm * 128, nw0 = n0 + wn * 64;
+    constexpr int LS = EPS_LS;
+    const int c8 = l & 7, r8 = l >> 3;
+    const int n_parts = G.N >> 6, slice = nw0 >> 6;
+    float vmax = 0.f;  // range guard (common.h)
+    f16x4 rh[2][4], rl[2][4];  // EPI_S_RESLN: residual pairs of the current and the next pass
+    auto res_load = [&](int p, int buf) {
+        const int y = p >> 1, x = p & 1;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const _Float16 *rp = G.res_hi + (size_t)(mw0 + y * 32 + it * 8 + r8) * G.ldr;
+            rh[buf][it] = *reinterpret_cast<const f16x4 *>(rp + pair_hi_col(nw0 + x * 32 + c8 * 4, G.N));
+            rl[buf][it] = *reinterpret_cast<const f16x4 *>(rp + pair_lo_col(nw0 + x * 32 + c8 * 4, G.N));
+        }
+    };
+    if constexpr (EPI == EPI_S_RESLN) res_load(0, 0);
+    f32x4 keep[4];  // EPI_S_RESLN: the x = 0 values of the pass's four rows (slice statistics need all 64 columns)
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+        const int y = p >> 1, x = p & 1;
+        if constexpr (EPI == EPI_S_RESLN)
+            if (p + 1 < 8) res_load(p + 1, (p + 1) & 1);
+        const f32x4 v0 = *reinterpret_cast<const f32x4 *>(vec + wn * 64 + x * 32 + c8 * 4);        // bias (b' for the folded ones)
+        const f32x4 v1 = *reinterpret_cast<const f32x4 *>(vec + 256 + wn * 64 + x * 32 + c8 * 4);  // csum | gamma
+        f32x4 v2 = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (EPI == EPI_S_RESLN) v2 = *reinterpret_cast<const f32x4 *>(vec + 512 + wn * 64 + x * 32 + c8 * 4);  // beta
+        epi_sync<true>();
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+            const f32x16 &a = acc[x][y];
+            *reinterpret_cast<f32x4 *>(slab + i * LS + 8 * rq + 4 * g) = f32x4{a[4 * rq], a[4 * rq + 1], a[4 * rq + 2], a[4 * rq + 3]};
+        }
+        epi_sync<true>();
+        f32x4 vv[4];
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int rr = it * 8 + r8;
+            f32x4 v = *reinterpret_cast<const f32x4 *>(slab + rr * LS + c8 * 4);
+            const float mean = stats[2 * (wm * 128 + y * 32 + rr)], rstd = stats[2 * (wm * 128 + y * 32 + rr) + 1];
+            const size_t row = (size_t)(mw0 + y * 32 + rr);
+            const int n = nw0 + x * 32 + c8 * 4;
+            if constexpr (EPI == EPI_S_RESLN) {
+                const int b = p & 1;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float a = rstd * v1[e];
+                    const float res = (float)rh[b][it][e] + (float)rl[b][it][e] * PAIR_LO_INV;  // exact in fp32: 22 bits
+                    v[e] = __builtin_fmaf(v[e], winv, __builtin_fmaf(res - mean, a, v0[e] + v2[e]));
+                }
+                range_track4(v, &vmax);
+                EPI_PAIR_STORE(v, G.out16 + row * G.ldc, G.N, n);
+                vv[it] = v;
+            } else {
+                const float mr = mean * rstd, rw = rstd * winv;  // r (acc winv) = acc (r winv): winv is a power of two
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(v[e], rw, __builtin_fmaf(-mr, v1[e], v0[e]));
+                if constexpr (EPI == EPI_S_QKV) {
+                    range_track4(v, &vmax);
+                    EPI_F32_STORE(reinterpret_cast<f32x4 *>(G.out32 + row * G.ldc + n), v);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = gelu_exact(v[e]);
+                    range_track4(v, &vmax);
+                    EPI_PAIR_STORE(v, G.out16 + row * G.ldc, G.N, n);
+                }
+            }
+        }
+        if constexpr (EPI == EPI_S_RESLN) {
+            if (x == 0) {
+#pragma unroll
+                for (int it = 0; it < 4; ++it) keep[it] = vv[it];
+            } else {
+                float s4[4], q4[4];
+                const bool lowq = c8 < 4;
+#pragma unroll
+                for (int it = 0; it < 4; ++it)
+                    s4[it] = slice64_sum(quad_sum((keep[it][0] + keep[it][1]) + (keep[it][2] + keep[it][3])),
+                                         quad_sum((vv[it][0] + vv[it][1]) + (vv[it][2] + vv[it][3])), lowq) * (1.0f / 64.0f);
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const float m64 = s4[it];
+                    const float a0 = keep[it][0] - m64, a1 = keep[it][1] - m64, a2 = keep[it][2] - m64, a3 = keep[it][3] - m64;
+                    const float d0 = vv[it][0] - m64, d1 = vv[it][1] - m64, d2 = vv[it][2] - m64, d3 = vv[it][3] - m64;
+                    q4[it] = slice64_sum(quad_sum((a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3)), quad_sum((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3)), lowq);
+                }
+                if (c8 == 0) {
+#pragma unroll
+                    for (int it = 0; it < 4; ++it)
+                        *reinterpret_cast<float2 *>(G.part_out + ((size_t)(mw0 + y * 32 + it * 8 + r8) * n_parts + slice) * 2) =
+                            make_float2(s4[it], q4[it]);
+                }
+            }
+        }
+    }
+    range_report(vmax, G.range_faults);
+}
+
 }  // namespace ance

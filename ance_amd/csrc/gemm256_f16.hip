@@ -310,6 +310,156 @@ __global__ void __launch_bounds__(G256_THREADS, 2) gemm256_split_kernel(const Ge
     GSTAMP(3);
 }
 
+// PERSISTENT, STREAMING form of the split GEMM (round 6; ANCE_GEMM_STREAM=1 -- measured flat, the kernel above stays the product).
+// One workgroup per CU walks its own sequence of output tiles; the K loop of tile i ends as Pipe256T::tiles_streaming -- its last
+// two K-tiles stage K-tile 0 and A0 / B0 / B1 of K-tile 1 of tile i + 1 in the steady-state rhythm -- so tile i's epilogue runs with
+// the next tile's first operand bytes in flight and the next K loop starts where a steady-state K-tile starts: no pipeline fill
+// (3 us of a 58-62 us tile at K = 768), no workgroup launch between two tiles, no launch ramp; the epilogue's stores drain under
+// the next tile's first MFMA phase.  What that costs is LDS: the stage buffers are busy during the epilogue, so the epilogue lives
+// in a quarter of the slab space (gemm256_epilogue_split32: 32 x 32 passes) --
+//   [0, 128 KiB)          stage buffers; the A-half1 slot of buffer 1 is free between two tiles (K-tile 1's A-half1 is staged by
+//                         P0 of K-tile 0): slabs of waves 0-2
+//   STATS 2 KiB, VEC 3 KiB   (mean, rstd) of the tile's 256 tokens; bias | csum or gamma | beta of its 256 features
+//   R 27 KiB              during the K loop the slice partials of the tile's tokens (24 KiB, LDS-DMA issued after the previous
+//                         epilogue, retired by the pipeline's counted waits); during the epilogue the slabs of waves 3-7
+// = 160 KiB exactly.  Tile order: workgroup b is on XCD b & 7 (round-robin dispatch) and takes the virtual blocks
+// ((i * slots + (b >> 3)) << 3) | xcd, i = 0, 1, ... of tile_of_block's order -- at any time the 32 CUs of an XCD work on the 32
+// consecutive blocks the launch-per-tile kernel would have had in flight there, so the L2 behaviour (and the N-split order of FFN1)
+// carries over.  Results are bit-identical to the kernel above (same K order, same epilogue arithmetic, same reduction trees).
+constexpr int EPS_STATS = 32768;                 // floats: above the 128 KiB of stage buffers
+constexpr int EPS_VEC = EPS_STATS + 512;
+constexpr int EPS_R = EPS_VEC + 768;             // 27,648 bytes: slice partials (24 KiB) | slabs of waves 3-7 (5 x 4,608 B)
+constexpr size_t GS_LDS_BYTES = (size_t)(EPS_R + 256 * 24 + 768) * sizeof(float);  // 163,840
+static_assert(GS_LDS_BYTES == 160 * 1024, "the streaming kernel uses the whole LDS of a CU");
+static_assert(5 * EPS_SLAB_FLOATS <= 256 * 24 + 768 && 3 * EPS_SLAB_FLOATS * 4 <= 16384, "slab layout");
+#ifndef ANCE_STREAM_LOOSE_FIRST
+#define ANCE_STREAM_LOOSE_FIRST 1  // 1: K-tile 0 of a prefetched tile does not wait for the previous epilogue's stores (pipe256.h: tile2); 0: steady-state waits
+#endif
+// vector-memory operations EVERY wave issues between the hand-over's last LDS-DMA and K-tile 0 of the next output tile: the
+// epilogue's stores (gemm256_epilogue_split32: 8 passes x 4 fp32 stores, x 4 x 2 pair stores, RESLN + 64 loads + 16 statistics) and
+// the three LDS-DMAs of the slice partials (eps_issue; the vector DMAs are issued by three waves only and do not count)
+template <int EPI>
+constexpr int eps_foreign_ops() { return (EPI == EPI_S_QKV ? 32 : EPI == EPI_S_GELU ? 64 : 144) + 3; }
+
+template <int EPI_>
+__device__ __forceinline__ void eps_issue(const GemmArgs &G, float *smem_f, int m0, int n0, int w, int l) {
+    typedef __attribute__((address_space(3))) void lds_t;
+    typedef const __attribute__((address_space(1))) void glb_t;
+    const float *psrc = G.part_in + (size_t)m0 * 24;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int piece = w + 8 * j;  // 24 pieces of 1 KiB
+        __builtin_amdgcn_global_load_lds((glb_t *)(psrc + piece * 256 + l * 4), (lds_t *)(smem_f + EPS_R + piece * 256), 16, 0, 0);
+    }
+    if (w == 0) __builtin_amdgcn_global_load_lds((glb_t *)(G.bias + n0 + l * 4), (lds_t *)(smem_f + EPS_VEC), 16, 0, 0);
+    if (EPI_ == EPI_S_RESLN) {
+        if (w == 1) __builtin_amdgcn_global_load_lds((glb_t *)(G.res_gamma + n0 + l * 4), (lds_t *)(smem_f + EPS_VEC + 256), 16, 0, 0);
+        if (w == 2) __builtin_amdgcn_global_load_lds((glb_t *)(G.res_beta + n0 + l * 4), (lds_t *)(smem_f + EPS_VEC + 512), 16, 0, 0);
+    } else {
+        if (w == 1) __builtin_amdgcn_global_load_lds((glb_t *)(G.csum + n0 + l * 4), (lds_t *)(smem_f + EPS_VEC + 256), 16, 0, 0);
+    }
+}
+
+// workgroup barrier that does NOT drain the vector-memory counter (the next tile's LDS-DMAs and this tile's stores stay in flight)
+__device__ __forceinline__ void eps_barrier() {
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int EPI>
+__global__ void __launch_bounds__(G256_THREADS, 2) gemm256_split_stream_kernel(const GemmArgs G, const int n_blocks) {
+    extern __shared__ __attribute__((aligned(16))) float smem_f[];
+    _Float16 *smem = reinterpret_cast<_Float16 *>(smem_f);
+    const int tid = threadIdx.x;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l = tid & 63;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslots = gridDim.x >> 3;
+    int round = 0;
+    // next valid tile of this workgroup's sequence (virtual blocks past the matrix -- the padding of tile_of_block's order -- are skipped)
+    auto next_tile = [&](int *mt, int *nt) -> bool {
+        for (;;) {
+            const int b = ((round * nslots + slot) << 3) | xcd;
+            if (b >= n_blocks) return false;
+            ++round;
+            if (tile_of_block(G, b, mt, nt)) return true;
+        }
+    };
+    int mt, nt;
+    if (!next_tile(&mt, &nt)) return;
+    Pipe256T<PipeSrcStream, false, true, true, true> P;
+    P.init(smem, w, l);
+    P.S.ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16 *>(G.A), 0, (int)((uint32_t)G.M * (uint32_t)G.lda * 2u), 0x00020000);
+    P.S.rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16 *>(G.B), 0, (int)((uint32_t)G.N * (uint32_t)G.ldb * 2u), 0x00020000);
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int r = pipe_stage_row(w, l, j), ch = pipe_stage_chunk(r, l);
+            P.S.voff[h][j] = (uint32_t)(pipe_a_tile_row(h, r) * G.lda + ch) * 2u;
+            P.S.voff[2 + h][j] = (uint32_t)(pipe_b_tile_row(h, r) * G.ldb + ch) * 2u;
+        }
+    const int NK = G.K / 32;  // K-tile = 64 halves of a blocked pair row = 32 k of hi and lo
+    P.S.NK = NK;
+    P.S.a_cur = P.S.a_nxt = (uint32_t)mt * 256u * (uint32_t)G.lda * 2u;
+    P.S.b_cur = P.S.b_nxt = (uint32_t)nt * 256u * (uint32_t)G.ldb * 2u;
+    const float winv = G.wscale_inv ? *G.wscale_inv : 1.0f;
+    // (slab of a wave: waves 0-2 in the A-half1 slot of stage buffer 1, waves 3-7 in R)
+    eps_issue<EPI>(G, smem_f, mt * TM, nt * TN, w, l);
+    if constexpr (ANCE_STREAM_LOOSE_FIRST) P.prologue_landed(); else P.prologue();
+    P.enter();
+    for (;;) {
+        int mtn = 0, ntn = 0;
+        const bool have_n = next_tile(&mtn, &ntn);
+        f32x16 acc[2][4];
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+            for (int y = 0; y < 4; ++y) acc[x][y] = f32x16{0};
+        if (have_n) {
+            P.S.a_nxt = (uint32_t)mtn * 256u * (uint32_t)G.lda * 2u;
+            P.S.b_nxt = (uint32_t)ntn * 256u * (uint32_t)G.ldb * 2u;
+        }
+        constexpr int F = ANCE_STREAM_LOOSE_FIRST ? eps_foreign_ops<EPI>() : 0;
+        constexpr int VM0F = 6 + F > 63 ? 63 : 6 + F, VM1F = 2 + F > 63 ? 63 : 2 + F;
+        // (the first tile of the workgroup comes from prologue_landed: nothing in flight, the loose waits of its K-tile 0 are trivially enough)
+        if (have_n) P.template tiles_streaming<VM0F, VM1F>(NK, acc); else P.template tiles_final<VM0F, VM1F>(NK, acc);
+        P.leave();
+        // (the lane id is laundered through an empty asm: hipcc otherwise hoists every lane-derived address of the epilogue out of the
+        // tile loop, runs out of registers next to the 128 accumulators and reloads them from scratch here -- and a scratch reload is a
+        // vmcnt(0) wait that drains the next tile's prefetch; ip_topk_fast.hip found the same)
+        int lf = l;
+        asm volatile("" : "+v"(lf));
+        const int tf = (w << 6) | lf;
+        // (the same for the kernel arguments: ~50 SGPRs of pointers and strides that only the epilogue uses would otherwise stay live
+        // across the K loop -- re-read from the kernarg segment per tile instead)
+        typedef const __attribute__((address_space(4))) GemmArgs *kernarg_ptr_t;
+        kernarg_ptr_t gp = (kernarg_ptr_t)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(gp));
+        const GemmArgs Ge = *gp;
+        // (mean, rstd) of the tile's tokens from their slice partials (in R since before this K loop), published by one barrier;
+        // after it R belongs to the slabs
+        if (tf < 256) {
+            float mean, rstd;
+            stats_from_parts(smem_f + EPS_R + tf * 24, Ge.ln_eps, &mean, &rstd);
+            smem_f[EPS_STATS + 2 * tf] = mean;
+            smem_f[EPS_STATS + 2 * tf + 1] = rstd;
+        }
+        eps_barrier();
+        float *slab = w < 3 ? smem_f + (PIPE_BUF_HALVES + PIPE_HALF_HALVES) / 2 + w * EPS_SLAB_FLOATS : smem_f + EPS_R + (w - 3) * EPS_SLAB_FLOATS;
+        gemm256_epilogue_split32<EPI>(Ge, acc, slab, smem_f + EPS_STATS, smem_f + EPS_VEC, mt * TM, nt * TN, w, lf, winv);
+        if (!have_n) break;
+        eps_barrier();  // every wave is done with STATS, VEC and its slab: R and the A-half1 slot may be refilled
+        mt = mtn;
+        nt = ntn;
+        P.S.a_cur = P.S.a_nxt;
+        P.S.b_cur = P.S.b_nxt;
+        eps_issue<EPI>(Ge, smem_f, mt * TM, nt * TN, w, lf);
+        P.enter();
+    }
+}
+
 template <int EPI, bool ABLATE>
 __global__ void __launch_bounds__(G256_THREADS, 2) gemm256_f16_kernel(const GemmArgs G) {
     extern __shared__ __attribute__((aligned(16))) float smem_f[];
@@ -389,6 +539,29 @@ unsigned long long *g_gemm_stamps_host = nullptr;
 int g_gemm_stamps_epi = EPI_RESLN;  // which epilogue's launches are stamped (ance_debug_gemm_stamps_epi)
 #endif
 
+// ANCE_GEMM_STREAM=1: the persistent streaming split GEMM (measured flat against the launch-per-tile kernel and rejected:
+// DESIGN_REJECTED.md round 6; read once per process, ance_reload_env re-reads it)
+int g_gemm_stream = -1;
+bool gemm_stream_enabled() {
+    if (g_gemm_stream < 0) {
+        const char *e = getenv("ANCE_GEMM_STREAM");
+        g_gemm_stream = (e && e[0] == '1') ? 1 : 0;
+    }
+    return g_gemm_stream == 1;
+}
+int device_cu_count() {
+    static int cus[64] = {0};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 64) dev = 0;
+    if (cus[dev] == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8) n = 256;
+        cus[dev] = n;
+    }
+    return cus[dev];
+}
+
 template <bool ABLATE>
 int launch256(int epi, const GemmArgs &G, hipStream_t st) {
     const int MT = G.M / TM, NT = G.N / TN;
@@ -429,6 +602,26 @@ int launch256(int epi, const GemmArgs &G, hipStream_t st) {
             return check_launch("gemm256 attr");
         attr_mark(&attr_done[ai]);
     }
+    if (!ABLATE && epi >= EPI_S_QKV && gemm_stream_enabled() && G.K >= 96 && (uint64_t)G.M * (uint64_t)G.lda * 2u < (1ull << 31) &&
+        (uint64_t)G.N * (uint64_t)G.ldb * 2u < (1ull << 31)
+#ifdef ANCE_MEASURE
+        && !(epi == g_gemm_stamps_epi && g_gemm_stamps_host)
+#endif
+    ) {
+        void (*ks)(const GemmArgs, int) = epi == EPI_S_QKV    ? gemm256_split_stream_kernel<EPI_S_QKV>
+                                          : epi == EPI_S_GELU ? gemm256_split_stream_kernel<EPI_S_GELU>
+                                                              : gemm256_split_stream_kernel<EPI_S_RESLN>;
+        static unsigned long long sattr_done[3] = {0, 0, 0};
+        if (attr_needed(&sattr_done[epi - EPI_S_QKV])) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(ks), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GS_LDS_BYTES) != hipSuccess)
+                return check_launch("gemm256 stream attr");
+            attr_mark(&sattr_done[epi - EPI_S_QKV]);
+        }
+        const unsigned cus = (unsigned)device_cu_count() & ~7u;  // one workgroup per CU (160 KiB of LDS each), a multiple of the 8 XCDs
+        const unsigned grid = blocks < cus ? blocks : cus;
+        hipLaunchKernelGGL(ks, dim3(grid), dim3(G256_THREADS), GS_LDS_BYTES, st, G, (int)blocks);
+        return ANCE_OK;
+    }
     const size_t lds = epi >= EPI_RESLN ? G256_LDS_BYTES + (size_t)EPB_FLOATS * sizeof(float) : G256_LDS_BYTES;
 #ifdef ANCE_MEASURE
     if (epi == g_gemm_stamps_epi && g_gemm_stamps_host) {
@@ -443,6 +636,8 @@ int launch256(int epi, const GemmArgs &G, hipStream_t st) {
 }
 
 }  // namespace
+
+void reload_gemm_knobs() { g_gemm_stream = -1; }
 
 bool gemm256_applicable(const GemmArgs &G) {
     return G.M > 0 && G.N > 0 && G.K >= 2 * TK && G.M % TM == 0 && G.N % TN == 0 && G.K % TK == 0;

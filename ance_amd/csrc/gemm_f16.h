@@ -101,5 +101,6 @@ constexpr int EPB_FLOATS = EPB_VEC + 768;
 // 256 x 256 x 64 tile kernel of gemm256_f16.hip (M, N multiples of 256, K of 64).
 int launch_gemm_f16(int epi, const GemmArgs &args, hipStream_t stream);
 bool gemm256_applicable(const GemmArgs &args);
+void reload_gemm_knobs();  // re-read ANCE_GEMM_STREAM (ance_reload_env)
 
 }  // namespace ance

@@ -366,6 +366,7 @@ int ip_topk_fast(const float *d_x, int64_t n, int64_t row_base, const void *d_in
                  float *d_out_d, int64_t *d_out_i, void *d_workspace, size_t workspace_bytes, hipStream_t st);
 void set_fast_stamps(unsigned long long *d_stamps);
 void reload_fast_knobs();
+void reload_gemm_knobs();
 }
 
 extern "C" void ance_debug_search_stamps(void *d_stamps) { ance::set_fast_stamps(reinterpret_cast<unsigned long long *>(d_stamps)); }
@@ -384,6 +385,7 @@ static bool fast_enabled() {
 extern "C" void ance_reload_env(void) {
     g_search_exact = -1;
     ance::reload_fast_knobs();
+    ance::reload_gemm_knobs();
 }
 
 static size_t scan_workspace_bytes(int64_t n, int64_t nq, int k) {

@@ -1,42 +1,52 @@
-// Ping-pong main loop of the 256 x 256 x 64 fp16 MFMA tile (gfx950), shared by the encoder GEMM
-// (gemm256_f16.hip) and the search filter (ip_topk_fast.hip).
+// Ping-pong main loop of the 256 x 256 x 64 fp16 MFMA tile (gfx950), shared by the encoder GEMMs (gemm256_f16.hip: the split
+// GEMM of the default arithmetic and the fp16 GEMM of the fast mode) and the search filter (ip_topk_fast.hip).
 //
 //   acc[x][y] += sum_k  B[n][k] * A[m][k]      n = wn*64 + x*32 + (C-layout row)   m = wm*128 + y*32 + lane&31
 //
-// 8 waves (2 along m x 4 along n), 128 KiB of LDS = 2 K-tile buffers x 4 half-tiles of 128 rows x
-// 64 halves (16 KiB each): A-half h holds the 64-row blocks {h, h+2} of the A tile (so a wave's
-// fragments y = 0,1 come from A-half 0 and y = 2,3 from A-half 1), B-half h holds the 32-row
-// blocks {h, h+2, h+4, h+6} of the B tile (x = h).  A K-tile is consumed in four phases, one
-// 64 x 32 output quadrant of every wave each:
+// 8 waves (2 along m x 4 along n), 128 KiB of LDS = 2 K-tile buffers x 4 half-tiles of 128 rows x 64 halves (16 KiB each):
+// A-half h holds the 64-row blocks {h, h+2} of the A tile (so a wave's fragments y = 0,1 come from A-half 0 and y = 2,3 from
+// A-half 1), B-half h holds the 32-row blocks {h, h+2, h+4, h+6} of the B tile (x = h).  Half-tiles are staged by LDS-DMA
+// (16 bytes per lane, lane-linear LDS image, XOR swizzle on the SOURCE address) 2-3 phases ahead with counted s_waitcnt vmcnt(N),
+// never 0 in steady state; the four waves with wm = 1 run one barrier behind the four with wm = 0, so on every SIMD one wave is
+// in its MFMA half-phase while the other one reads LDS.
 //
+// THE SCHEDULE OF THE PRODUCT KERNELS IS THE COARSE ONE (COARSE: two phases per K-tile, both B halves of a K-tile in registers):
+//   phase P0: read A-half0, B-half0, B-half1   MFMAs on acc[0][0..1], acc[1][0..1]   + stage A-half1 of tile t+1
+//   phase P1: read A-half1                     MFMAs on acc[1][2..3], acc[0][2..3]   + stage A0, B0, B1 of tile t+2
+// with 16 MFMAs per phase on plain fp16 operands and -- PAIR3, the split GEMM of the DEFAULT arithmetic -- 24: both operands are
+// BLOCKED pair rows (common.h: 32 columns of hi, then the same 32 columns of lo), so the 64 halves of an LDS row are
+//   [hi k 0..15 | hi k 16..31 | lo k 0..15 | lo k 16..31]          (fragment index s = 0..3)
+// i.e. a K-tile is a 32-deep k-slice of hi AND lo of both operands, and per output quadrant and k-step j the wave issues the three
+// products  hi_j x hi_j,  lo_j x hi_j,  hi_j x lo_j  (fragment pairs (j, j), (j + 2, j), (j, j + 2)) into ONE accumulator: four
+// operand tiles staged and read once for three products.  Staging, ds_reads, barriers and waits are identical in both forms.
+//   RAW  the wait at the end of the P1 reads of tile t-1 (vmcnt(2)) leaves only A-half1 of tile t in flight, so A0 / B0 / B1 of
+//        tile t are retired and the following barrier publishes them; the wait at the end of the P0 reads of tile t (vmcnt(6))
+//        leaves only A0 / B0 / B1 of tile t+1 in flight, so A-half1 of tile t is retired before the barrier that precedes its read.
+//   WAR  a half-tile last read in phase p is restaged in the MFMA half-phase of phase p+1 at the earliest (A0 / B0 / B1 read in
+//        P0 of tile t, restaged in P1 of tile t; A1 read in P1 of tile t, restaged in P0 of t+1): the last ds_read of it (by the
+//        wm = 1 group, one slot later) has returned before that wave's MFMAs of the next slot are issued (they consume it), and a
+//        barrier separates that slot from the restage.
+// STREAMING (tiles_streaming + a source policy that maps K-tile t >= NK onto what follows): the K loop of the NEXT tile of a
+// workgroup's sequence -- the next corpus tile of the search filter, the next OUTPUT tile of the persistent split GEMM -- is
+// prefetched by the last two K-tiles of the current one, in the steady-state rhythm; the epilogue / filter step runs with those
+// LDS-DMAs in flight and the next K loop starts without a pipeline fill.
+//
+// The original FOUR-phase schedule (one 64 x 32 output quadrant of every wave per phase, 8 MFMAs each, B-half0 read twice or
+// kept in 16 registers: KEEP_B0) is what the measurement builds of the fp16 GEMM and the search filter still instantiate:
 //   phase c0: read A-half0 + B-half0   MFMA acc[0][0..1]  + stage B-half0 of tile t+1
 //   phase c1: read B-half1             MFMA acc[1][0..1]  + stage A-half0 of tile t+2
 //   phase c2: read A-half1             MFMA acc[1][2..3]  + stage B-half1 of tile t+2
 //   phase c3: read B-half0 (again)     MFMA acc[0][2..3]  + stage A-half1 of tile t+2
-//
-// Every phase is  { ds_reads }  s_barrier  { 8 MFMA with 2 global_load_lds issued between them }
-// s_barrier, plus ONE s_waitcnt vmcnt(4) per K-tile (end of the c3 reads).  The four waves with
-// wm = 1 run one barrier behind the four with wm = 0, so on every SIMD one wave is in its MFMA
-// half-phase while the other one reads LDS: the matrix pipe never waits for a ds_read, and staged
-// half-tiles stay in flight across barriers (4-7 phases ahead, counted vmcnt, never 0 in steady
-// state).  Where the LDS-DMAs are issued was chosen by cycle counts (profiles/
-// r01_gemm_schedule_variants_cycles.txt): between the MFMAs 1.36 M cycles per XCD on 8192^3, in the
-// read half-phase 1.57-1.96 M, one in each 1.79 M, at the start / end of the MFMA half-phase 1.48-1.50 M;
-// the wm stagger itself is worth 1.36 vs 1.78 M and the two-phase loop this replaced took 1.88 M.
-//
-// Hazards (slot = interval between two barriers; wm=0 reads phase p in slot 2p and computes it in
-// slot 2p+1, wm=1 one slot later):
-//   RAW  the wait at the end of the c3 reads of tile t-1 leaves at most two half-tiles in flight
-//        (A-half0 and B-half1 of tile t+1, the last ones issued): every wave has then retired its
-//        pieces of all four half-tiles of tile t, and the barrier that follows publishes them before
-//        the first read of tile t.
-//   WAR  a half-tile last read in phase p is restaged in the MFMA half-phase of phase p+1 at the
-//        earliest (wm=0: slot 2p+3).  The last ds_read of it (wm=1, slot 2p+1) has returned before
-//        that wave's MFMAs of slot 2p+2 are issued (they consume it), and the barrier ending slot
-//        2p+2 comes before slot 2p+3.
+// Every phase is  { ds_reads }  s_barrier  { MFMAs with the LDS-DMAs issued between them }  s_barrier.  Where the LDS-DMAs are
+// issued was chosen by cycle counts (profiles/attic/r01_gemm_schedule_variants_cycles.txt): between the MFMAs 1.36 M cycles per
+// XCD on 8192^3, in the read half-phase 1.57-1.96 M, at the start / end of the MFMA half-phase 1.48-1.50 M; the wm stagger itself
+// is worth 1.36 vs 1.78 M and the two-phase loop this replaced took 1.88 M.  Its hazards (slot = interval between two barriers;
+// wm = 0 reads phase p in slot 2p and computes it in slot 2p+1, wm = 1 one slot later): RAW -- the wait at the end of the c3 reads
+// of tile t-1 leaves at most two half-tiles in flight (A-half0 and B-half1 of tile t+1), so every wave has retired its pieces of
+// all four half-tiles of tile t and the barrier that follows publishes them; WAR -- as above.
 // Needs NK >= 2 K-tiles.  The last two tiles are peeled (nothing left to stage, smaller counts).
-// tests/test_pipe_schedule_model.py replays these tables (prologue, steady state, peeled tiles, both wave groups)
-// on a slot timeline and asserts the RAW / WAR conditions for every K-tile count.
+// tests/test_pipe_schedule_model.py replays these tables (prologue, steady state, peeled tiles, streaming hand-over, both wave
+// groups, every form) on a slot timeline and asserts the RAW / WAR conditions for every K-tile count.
 #pragma once
 #include "common.h"
 
@@ -102,6 +112,43 @@ struct PipeSrcDesc {
     }
 };
 
+// Source policy of the STREAMING (persistent) GEMM: one descriptor per operand MATRIX (wave-uniform), the first row of the
+// workgroup's current and next output tile as byte offsets in SGPRs.  K-tile t < NK belongs to the current output tile, K-tile
+// t >= NK is K-tile t - NK of the NEXT one (the hand-over of Pipe256T::tiles_streaming).  Needs matrices below 2 GiB.
+struct PipeSrcStream {
+    __amdgpu_buffer_rsrc_t ra, rb;
+    uint32_t voff[4][2];  // [A0 A1 B0 B1][piece]: offset inside the 256-row tile
+    int NK;
+    uint32_t a_cur, b_cur, a_nxt, b_nxt;  // (tile row) * (row stride) * 2 bytes
+    __device__ __forceinline__ uint32_t off_a(int t) const { return t >= NK ? a_nxt + (uint32_t)(t - NK) * 128u : a_cur + (uint32_t)t * 128u; }
+    __device__ __forceinline__ uint32_t off_b(int t) const { return t >= NK ? b_nxt + (uint32_t)(t - NK) * 128u : b_cur + (uint32_t)t * 128u; }
+    template <int TYPE, int J>
+    __device__ __forceinline__ void issue(int t, pipe_lds_t *dst) const {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(TYPE < 2 ? ra : rb, dst, 16, voff[TYPE][J], (int)(TYPE < 2 ? off_a(t) : off_b(t)), 0, 0);
+    }
+    // The LDS-DMAs of the coarse schedule sit between MFMAs, fenced by sched_barriers: the scalar compare / select / add chain of
+    // off_a / off_b in front of each of the eight costs the wave issue time exactly there (measured on the first form of the
+    // streaming GEMM: +14 scalar instructions per K-tile, FFN2 -- 96 K-tiles per output tile -- 2-4 % slower than the launch-per-tile
+    // kernel).  prepare(t) computes the three offsets a K-tile needs (A-half1 of tile t + 1; A and B of tile t + 2) once, in the read
+    // half-phase, and issue_pre picks one by the half-tile's type.
+    static constexpr bool PRECOMPUTE = true;
+    uint32_t so_a1, so_a2, so_b2;
+    __device__ __forceinline__ void prepare(int t) {
+        so_a1 = off_a(t + 1);
+        so_a2 = off_a(t + 2);
+        so_b2 = off_b(t + 2);
+    }
+    template <int TYPE, int J>
+    __device__ __forceinline__ void issue_pre(pipe_lds_t *dst) const {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(TYPE < 2 ? ra : rb, dst, 16, voff[TYPE][J], (int)(TYPE == 1 ? so_a1 : TYPE == 0 ? so_a2 : so_b2), 0, 0);
+    }
+};
+
+template <class S, class = void>
+struct pipe_src_precomputes { static constexpr bool value = false; };
+template <class S>
+struct pipe_src_precomputes<S, decltype((void)S::PRECOMPUTE)> { static constexpr bool value = S::PRECOMPUTE; };
+
 // SRC provides  template <int TYPE, int J> void issue(int t, pipe_lds_t *dst)  : the LDS-DMA (16 bytes per lane, 1 KiB per
 // wave, lane-linear at dst) of piece J of half-tile TYPE (0 A-half0, 1 A-half1, 2 B-half0, 3 B-half1) of K-tile t.
 // DBG compiles measurement ablations in (dbg bit 1: no MFMA, bit 3: no staging); product code uses DBG = false.
@@ -149,11 +196,12 @@ struct Pipe256T {
         rb = (wn * 32 + i) * 64;
     }
 
-    template <int TYPE, int J>
+    template <int TYPE, int J, bool PRE = false>
     __device__ __forceinline__ void stage_piece(int t) {
         if (DBG && (dbg & 8)) return;            // ablation: stage nothing (prologue included)
         _Float16 *dst = smem + (t & 1) * PIPE_BUF_HALVES + TYPE * PIPE_HALF_HALVES + (w + 8 * J) * 512;
-        S.template issue<TYPE, J>(t, (pipe_lds_t *)dst);
+        if constexpr (PRE && pipe_src_precomputes<SRC>::value) S.template issue_pre<TYPE, J>((pipe_lds_t *)dst);  // offsets of S.prepare(t)
+        else S.template issue<TYPE, J>(t, (pipe_lds_t *)dst);
     }
     template <int TYPE>
     __device__ __forceinline__ void stage(int t) {
@@ -276,12 +324,12 @@ struct Pipe256T {
             if (step % GAP == 0 && step / GAP < 2 * n_stage) {
                 const int pc = step / GAP;
                 __builtin_amdgcn_sched_barrier(0);
-                if (pc == 0) stage_piece<types[0], 0>(ts);
-                if (pc == 1) stage_piece<types[0], 1>(ts);
-                if (pc == 2) stage_piece<types[1], 0>(ts);
-                if (pc == 3) stage_piece<types[1], 1>(ts);
-                if (pc == 4) stage_piece<types[2], 0>(ts);
-                if (pc == 5) stage_piece<types[2], 1>(ts);
+                if (pc == 0) stage_piece<types[0], 0, true>(ts);
+                if (pc == 1) stage_piece<types[0], 1, true>(ts);
+                if (pc == 2) stage_piece<types[1], 0, true>(ts);
+                if (pc == 3) stage_piece<types[1], 1, true>(ts);
+                if (pc == 4) stage_piece<types[2], 0, true>(ts);
+                if (pc == 5) stage_piece<types[2], 1, true>(ts);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -290,8 +338,16 @@ struct Pipe256T {
         __builtin_amdgcn_sched_barrier(0);
     }
 
-    template <int MODE>
+    // VM0 / VM1: the P0 / P1 waits of MODE 0 / 1 -- 6 and 2 in steady state (P0 leaves A0 B0 B1 of tile t+1 in flight, P1 A-half1 of
+    // tile t+1).  The FIRST K-tile of an output tile that was prefetched under an epilogue (tiles_streaming hand-over) has that
+    // epilogue's loads / stores and the parameter block's LDS-DMAs in the counter as well, YOUNGER than the half-tiles these two
+    // waits are for (A-half1 of tile t; A0 B0 B1 of tile t+1 -- all issued before the epilogue): the kernel may add the number of
+    // vector-memory operations EVERY wave is sure to have issued in between, capped at the counter's 63.  Larger counts only avoid
+    // waiting for the epilogue's stores to drain (vmcnt retires in order); from P0 of tile t+1 on the waits are the steady-state
+    // ones -- A-half1 of tile t+1 is younger than those stores.
+    template <int MODE, int VM0 = 6, int VM1 = 2>
     __device__ __forceinline__ void tile2(int t, f32x16 (&acc)[2][4]) {
+        if constexpr (pipe_src_precomputes<SRC>::value) S.prepare(t);
         if constexpr (PAIR3 && PIPE_PAIR3_EARLY > 0) {
             // in flight when a tile starts (oldest first): A1(t), A0 B0 B1 (t+1) -- what the prologue leaves, too
             // P0
@@ -331,11 +387,11 @@ struct Pipe256T {
         read_a<0>(t);
         read_b<0>(t);
         read_b<1>(t);
-        if constexpr (MODE <= 1) PIPE_WAIT_VM(6); else PIPE_WAIT_VM(0);
+        if constexpr (MODE <= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM0) : "memory"); else PIPE_WAIT_VM(0);
         if constexpr (MODE <= 1) mfma16<0, 1, -1, -1>(acc, t + 1); else mfma16<0, -1, -1, -1>(acc, t + 1);
         // P1
         read_a<1>(t);
-        if constexpr (MODE <= 1) PIPE_WAIT_VM(2);
+        if constexpr (MODE <= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM1) : "memory");
         if constexpr (MODE == 0) mfma16<1, 0, 2, 3>(acc, t + 2); else mfma16<1, -1, -1, -1>(acc, t + 2);
     }
 
@@ -359,6 +415,17 @@ struct Pipe256T {
             __builtin_amdgcn_sched_barrier(0);
         }
     }
+    // coarse schedule: the prologue's half-tiles (K-tile 0, A0 B0 B1 of K-tile 1) with ALL of them retired and published -- what a
+    // K-tile 0 with loose waits (tile2: VM0 / VM1) needs when no epilogue preceded it
+    __device__ __forceinline__ void prologue_landed() {
+        static_assert(COARSE, "coarse schedule only");
+        stage<0>(0); stage<2>(0); stage<3>(0); stage<1>(0);
+        stage<0>(1); stage<2>(1); stage<3>(1);
+        PIPE_WAIT_VM(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    }
     // enter / leave the staggered section: wm = 1 runs one barrier behind wm = 0 in between
     __device__ __forceinline__ void enter() {
         __builtin_amdgcn_sched_barrier(0);
@@ -373,15 +440,31 @@ struct Pipe256T {
     // K-tiles 0..NK-1 of a stream that CONTINUES (the source policy maps t >= NK onto what follows):
     // on return K-tiles NK and NK+1 are staged exactly as the prologue leaves tiles 0 and 1 (the wait
     // of the last c3 has retired tile NK).
+    // VM0L / VM1L (coarse schedule, != 6 / 2): K-tile 0 was prefetched under an epilogue and waits with these counts (tile2).  The
+    // FIRST output tile of a persistent workgroup then starts from prologue_landed (every LDS-DMA of the prologue retired: a loose
+    // wait has nothing to wait for), so that K-tile 0 is the same code for every output tile.
+    template <int VM0L = 6, int VM1L = 2>
     __device__ __forceinline__ void tiles_streaming(int NK, f32x16 (&acc)[2][4]) {
-        for (int t = 0; t < NK; ++t) {
-            if constexpr (COARSE) tile2<0>(t, acc); else tile<0>(t, acc);
+        if constexpr (COARSE && (VM0L != 6 || VM1L != 2)) {
+            tile2<0, VM0L, VM1L>(0, acc);
+            for (int t = 1; t < NK; ++t) tile2<0>(t, acc);
+        } else {
+            for (int t = 0; t < NK; ++t) {
+                if constexpr (COARSE) tile2<0>(t, acc); else tile<0>(t, acc);
+            }
         }
     }
     // K-tiles T0..NK-1 of a stream that ENDS (T0 even: the buffer parity of a tile is t & 1; NK - T0 >= 2): nothing beyond
     // NK-1 is staged, no LDS-DMA left in flight.
+    // (VM0L / VM1L as tiles_streaming; they need NK - T0 >= 3: K-tile T0 is then a steady-state tile)
+    template <int VM0L = 6, int VM1L = 2>
     __device__ __forceinline__ void tiles_final(int NK, f32x16 (&acc)[2][4], int T0 = 0) {
-        if constexpr (COARSE) {
+        if constexpr (COARSE && (VM0L != 6 || VM1L != 2)) {
+            tile2<0, VM0L, VM1L>(T0, acc);
+            for (int t = T0 + 1; t < NK - 2; ++t) tile2<0>(t, acc);
+            tile2<1>(NK - 2, acc);
+            tile2<2>(NK - 1, acc);
+        } else if constexpr (COARSE) {
             for (int t = T0; t < NK - 2; ++t) tile2<0>(t, acc);
             tile2<1>(NK - 2, acc);
             tile2<2>(NK - 1, acc);

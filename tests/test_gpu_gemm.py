@@ -229,3 +229,52 @@ def test_mfma_keeps_f16_subnormals():
     got = out.double()
     assert float(want.min()) > 0
     assert torch.equal(got, want[:, None].expand(M, N).float().double()), (float(got.abs().max()), float(want.max()))
+
+
+def _split_raw(epi, M, N, K, seed, stream, monkeypatch):
+    """One launch of the split GEMM through its test hook, with the persistent streaming kernel (the product's) or the
+    launch-per-tile kernel (ANCE_GEMM_STREAM=0); returns the raw output buffers."""
+    from ance_amd import _lib
+    monkeypatch.setenv("ANCE_GEMM_STREAM", "1" if stream else "0")
+    _lib.reload_env()
+    L = _lib.lib()
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    ap = _pair_rows(*_pair(torch.randn((M, K), generator=g, device="cuda")))
+    bp = _pair_rows(*_pair(torch.randn((N, K), generator=g, device="cuda") * 0.02 * 2.0 ** 17))
+    winv = torch.tensor([2.0 ** -17], dtype=torch.float32, device="cuda")
+    bias, vec1, vec2 = (torch.randn(N, generator=g, device="cuda") for _ in range(3))
+    part = torch.empty((M, 12, 2), device="cuda")
+    part[:, :, 0] = torch.randn((M, 12), generator=g, device="cuda") * 0.1
+    part[:, :, 1] = 64.0 * (0.5 + torch.rand((M, 12), generator=g, device="cuda"))
+    rp = _pair_rows(*_pair(torch.randn((M, N), generator=g, device="cuda")))
+    out = torch.zeros((M, N), dtype=torch.float32, device="cuda") if epi == 8 else torch.zeros((M, 2 * N), dtype=torch.float16, device="cuda")
+    part_out = torch.zeros((M, max(N // 64, 1), 2), device="cuda")
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    rc = L.ance_debug_gemm_split(epi, P(ap), P(bp), M, N, K, P(bias), P(vec1), P(vec2), P(part), 1e-5, P(rp), P(out), P(part_out),
+                                 P(winv), _lib.current_stream_ptr())
+    _lib.check(rc, "ance_debug_gemm_split")
+    torch.cuda.synchronize()
+    return out, part_out
+
+
+@pytest.mark.parametrize("epi,shape", [(8, (256, 256, 128)), (8, (8192, 2304, 768)), (8, (16640, 2304, 768)), (9, (16384, 3072, 768)),
+                                       (9, (512, 3072, 768)), (10, (32768, 768, 768)), (10, (33024, 768, 3072)), (10, (256, 768, 128))])
+def test_streaming_split_gemm_equals_the_launch_per_tile_kernel(epi, shape, monkeypatch):
+    """Round 6: the persistent split GEMM (one workgroup per CU walking its output tiles, the next tile's first K-tiles staged
+    under the current epilogue, 32 x 32 epilogue passes in what LDS is left) against the launch-per-tile kernel it replaces:
+    same K order, same epilogue arithmetic, same reduction trees -- every output bit and every slice statistic identical, on
+    shapes with one tile per workgroup, with 2-3 tiles per workgroup, with a ragged last round, and with K = 128 / 768 / 3,072
+    (4 / 24 / 96 K-tiles)."""
+    from ance_amd import _lib
+    M, N, K = shape
+    try:
+        a, pa = _split_raw(epi, M, N, K, 5, True, monkeypatch)
+        b, pb = _split_raw(epi, M, N, K, 5, False, monkeypatch)
+    finally:
+        monkeypatch.delenv("ANCE_GEMM_STREAM", raising=False)
+        _lib.reload_env()
+    assert bool(torch.isfinite(a.float()).all())
+    assert torch.equal(a.view(torch.int16) if a.dtype == torch.float16 else a.view(torch.int32),
+                       b.view(torch.int16) if b.dtype == torch.float16 else b.view(torch.int32)), (epi, shape)
+    if epi == 10:
+        assert torch.equal(pa.view(torch.int32), pb.view(torch.int32)), "slice statistics differ"

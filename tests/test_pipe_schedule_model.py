@@ -180,3 +180,112 @@ def test_model_catches_a_broken_schedule():
         return ph
     with pytest.raises(AssertionError):
         replay(8, lazy_wait, coarse_prologue())
+
+
+# ---- persistent streaming GEMM (gemm256_f16.hip: gemm256_split_stream_kernel) -----------------------------------------------
+def replay_persistent(nk, n_out, f_actual, f_claimed, extra_ops_group1=1):
+    """A workgroup of the persistent split GEMM: ``n_out`` output tiles of ``nk`` K-tiles each on the coarse schedule.  The K loop
+    of output tile o hands over to tile o + 1 (its last two K-tiles stage K-tiles 0 and 1 of the next tile); between two tiles
+    both wave groups are aligned (leave()), run the epilogue -- which issues ``f_actual`` vector-memory operations per wave
+    (group 1: ``extra_ops_group1`` more, the waves that also fetch the parameter vectors) and uses the A-half1 slot of stage
+    buffer 1 as slab space -- and enter() the next K loop, whose K-tile 0 waits with 6 + f_claimed / 2 + f_claimed (capped at 63).
+    The first tile starts from prologue_landed (nothing in flight).  Asserts RAW / WAR as ``replay`` and that the slab slot is
+    neither still being read nor restaged while the epilogue owns it."""
+    assert nk % 2 == 0 and nk >= 4  # the hand-over keeps the buffer parity of K-tile 0 only for an even count
+    vm0 = min(63, 6 + f_claimed)
+    vm1 = min(63, 2 + f_claimed)
+    fifo = {0: [], 1: []}          # [(item, pieces)], oldest first; item = (type, global K-tile) or ("x", n)
+    retired = {0: {}, 1: {}}
+    read_done = {0: {}, 1: {}}
+    slab_busy = []                  # slots in which the epilogue owns (A1, buffer 1)
+    total = nk * n_out
+
+    def wait_pieces(g, n, slot):
+        out = sum(p for _, p in fifo[g])
+        r = out - n                 # pieces that must retire, oldest first (vmcnt retires in order)
+        while r > 0 and fifo[g]:
+            item, p = fifo[g][0]
+            if p > r:
+                fifo[g][0] = (item, p - r)   # part of a half-tile's pieces: the half-tile itself is not retired yet
+                r = 0
+            else:
+                fifo[g].pop(0)
+                r -= p
+                if item[0] != "x":
+                    retired[g][item] = slot
+
+    def stage(g, ht, slot):
+        typ, gt = ht
+        prev = (typ, gt - 2)
+        if gt >= 2:
+            for gg in (0, 1):
+                assert prev in read_done[gg] and read_done[gg][prev] < slot, "WAR: %s restaged in slot %d" % (ht, slot)
+        if typ == A1 and gt % 2 == 1:
+            assert slot not in slab_busy, "A-half1 slot of buffer 1 restaged while the epilogue's slabs live there"
+        fifo[g].append((ht, 2))
+
+    for g in (0, 1):  # prologue_landed
+        for ht in [(A0, 0), (B0, 0), (B1, 0), (A1, 0), (A0, 1), (B0, 1), (B1, 1)]:
+            retired[g][ht] = -1
+    base = 0
+    for o in range(n_out):
+        phases = []
+        for t in range(nk):
+            gt = o * nk + t
+            last = o == n_out - 1
+            mode = 0 if not (last and t >= nk - 2) else (1 if t == nk - 2 else 2)
+            p0, p1 = coarse(mode, gt)
+            if t == 0:
+                p0 = (p0[0], vm0, p0[2])
+                p1 = (p1[0], vm1, p1[2])
+            phases += [p0, p1]
+        for ls in range(2 * len(phases) + 2):
+            slot = base + ls
+            for g in (0, 1):
+                if (ls - g) % 2 == 0 and 0 <= (ls - g) // 2 < len(phases):
+                    reads, w = phases[(ls - g) // 2][0], phases[(ls - g) // 2][1]
+                    for ht in reads:
+                        for gg in (0, 1):
+                            assert ht in retired[gg] and retired[gg][ht] < slot, "RAW: %s read in slot %d (group %d: %s)" % (
+                                ht, slot, gg, retired[gg].get(ht))
+                    if w is not None:
+                        wait_pieces(g, w, slot)
+                if (ls - g) % 2 == 1 and 0 <= (ls - g - 1) // 2 < len(phases):
+                    reads, stages = phases[(ls - g - 1) // 2][0], phases[(ls - g - 1) // 2][2]
+                    for ht in reads:
+                        read_done[g].setdefault(ht, slot)
+                    for ht in stages:
+                        if ht[1] < total:
+                            stage(g, ht, slot)
+        base += 2 * len(phases) + 2
+        if o < n_out - 1:
+            # epilogue: its own slot (leave() aligned the groups; a barrier follows it)
+            for g in (0, 1):
+                assert read_done[g][(A1, o * nk + nk - 1)] < base, "slab written while A-half1 of the last K-tile is still read"
+                fifo[g] += [(("x", i), 1) for i in range(f_actual + (extra_ops_group1 if g == 1 else 0))]
+            slab_busy.append(base)
+            base += 1
+    for g in (0, 1):
+        assert not [it for it, _ in fifo[g] if it[0] != "x"], "LDS-DMAs left in flight: %s" % fifo[g]
+        for gt in range(total):
+            for typ in (A0, A1, B0, B1):
+                assert (typ, gt) in read_done[g]
+
+
+@pytest.mark.parametrize("nk", [4, 6, 8, 24])
+@pytest.mark.parametrize("n_out", [1, 2, 3])
+@pytest.mark.parametrize("f", [0, 35, 67, 147])
+def test_persistent_gemm_hand_over(nk, n_out, f):
+    """f = the foreign operations of gemm256_f16.hip: eps_foreign_ops (QKV 32 + 3, GELU 64 + 3, RESLN 144 + 3); 0 = the
+    steady-state waits on K-tile 0 (ANCE_STREAM_LOOSE_FIRST=0: correct whatever the epilogue issues)."""
+    replay_persistent(nk, n_out, f_actual=f, f_claimed=f)
+    replay_persistent(nk, n_out, f_actual=f + 20, f_claimed=f)   # an epilogue that issues MORE than claimed only waits longer
+    replay_persistent(nk, n_out, f_actual=max(f, 5), f_claimed=0)
+
+
+def test_persistent_model_catches_an_overstated_count():
+    """Claiming more foreign operations than every wave really issues lets K-tile 0 read a half-tile that is still in flight."""
+    with pytest.raises(AssertionError):
+        replay_persistent(8, 2, f_actual=30, f_claimed=35)
+    with pytest.raises(AssertionError):
+        replay_persistent(8, 3, f_actual=0, f_claimed=3, extra_ops_group1=0)

@@ -1,0 +1,38 @@
+// Probe of gfx950's LDS transpose read (ds_read_b64_tr_b16), the instruction the split attention reads its V fragments with
+// (csrc/attention.hip).  Every lane supplies the address of 4 contiguous halves; within each group of 16 lanes the 16 x 4 block
+// is delivered transposed.  Prints, for every lane and element, which (source lane, source element) the value came from, and
+// checks the rule the kernel relies on:   out[l][j] = in[16 (l / 16) + 4 j + (l % 16) / 4][(l % 16) % 4].
+//   hipcc --offload-arch=gfx950 -O2 -x hip tools/tr16_probe.cpp -o tools/tr16_probe && tools/tr16_probe
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef s16x4 __attribute__((address_space(3))) lds_s16x4;
+
+__global__ void probe(short *out) {
+    __shared__ __attribute__((aligned(16))) short lds[64 * 4];
+    const int l = threadIdx.x;
+    for (int j = 0; j < 4; ++j) lds[l * 4 + j] = (short)(l * 4 + j);  // value = 4 * source lane + source element
+    __syncthreads();
+    const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(lds + l * 4));
+    for (int j = 0; j < 4; ++j) out[l * 4 + j] = v[j];
+}
+
+int main() {
+    short *d, h[256];
+    if (hipMalloc(&d, sizeof(h)) != hipSuccess) return 2;
+    hipLaunchKernelGGL(probe, dim3(1), dim3(64), 0, 0, d);
+    if (hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess) return 2;
+    int bad = 0;
+    for (int l = 0; l < 64; ++l) {
+        printf("lane %2d:", l);
+        for (int j = 0; j < 4; ++j) {
+            const int src_lane = h[l * 4 + j] >> 2, src_elem = h[l * 4 + j] & 3;
+            const int want_lane = 16 * (l / 16) + 4 * j + (l % 16) / 4, want_elem = (l % 16) % 4;
+            printf("  (%2d,%d)%s", src_lane, src_elem, (src_lane == want_lane && src_elem == want_elem) ? "" : "!");
+            bad += !(src_lane == want_lane && src_elem == want_elem);
+        }
+        printf("\n");
+    }
+    printf("%s: %d mismatches against out[l][j] = in[16 (l / 16) + 4 j + (l %% 16) / 4][(l %% 16) %% 4]\n", bad ? "DIFFERENT RULE" : "rule confirmed", bad);
+    return bad ? 1 : 0;
+}
