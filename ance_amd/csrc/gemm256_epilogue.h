@@ -424,6 +424,11 @@ __device__ __forceinline__ float gelu_exact(float x) {
 // only pass through the 4 MB L2s on their way out, where they evict the operand panels the main loops re-read.  Same-box A/B
 // (profiles/r05_ab_nt_store.jsonl, three alternations): FFN1 -0.7 %, the attention that follows the QKV GEMM -2.5 %, step +0.3 %.
 // (ANCE_EPI_PLAIN_STORE: A/B builds with ordinary stores.)
+// The pair-row epilogues move 8 columns per lane (16-byte hi and 16-byte lo accesses): an epilogue is bound by the NUMBER of
+// vector-memory instructions its eight waves push through the CU's one address unit (~16 cycles each whatever their width) -- the
+// fp32 store epilogue of QKV (32 dwordx4 stores per wave and tile) measured 4 us, the GELU pair epilogue with 8-byte accesses (64
+// stores) 8.4 us, RESLN (64 loads + 64 stores + 32 statistics stores) 13.5 us.  Round 6: half as many, twice as wide.
+__device__ __forceinline__ f16x8 cat_f16x4(const f16x4 a, const f16x4 b) { return f16x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]}; }
 #ifndef ANCE_EPI_PLAIN_STORE
 __device__ __forceinline__ void epi_pair_store_nt(const f32x4 v, _Float16 *row, int W, int n) {
     f16x4 h, r;
@@ -431,12 +436,42 @@ __device__ __forceinline__ void epi_pair_store_nt(const f32x4 v, _Float16 *row, 
     __builtin_nontemporal_store(h, reinterpret_cast<f16x4 *>(row + pair_hi_col(n, W)));
     __builtin_nontemporal_store(r, reinterpret_cast<f16x4 *>(row + pair_lo_col(n, W)));
 }
+// columns n .. n + 7 (n a multiple of 8: inside one 32-column block)
+__device__ __forceinline__ void epi_pair_store8_nt(const f32x4 va, const f32x4 vb, _Float16 *row, int W, int n) {
+    f16x4 ha, ra, hb, rb;
+    pair_split4(va, &ha, &ra);
+    pair_split4(vb, &hb, &rb);
+    __builtin_nontemporal_store(cat_f16x4(ha, hb), reinterpret_cast<f16x8 *>(row + pair_hi_col(n, W)));
+    __builtin_nontemporal_store(cat_f16x4(ra, rb), reinterpret_cast<f16x8 *>(row + pair_lo_col(n, W)));
+}
 #define EPI_PAIR_STORE(v, row, W, n) epi_pair_store_nt(v, row, W, n)
+#define EPI_PAIR_STORE8(va, vb, row, W, n) epi_pair_store8_nt(va, vb, row, W, n)
 #define EPI_F32_STORE(p, v) __builtin_nontemporal_store(v, p)
 #else
+__device__ __forceinline__ void epi_pair_store8(const f32x4 va, const f32x4 vb, _Float16 *row, int W, int n) {
+    f16x4 ha, ra, hb, rb;
+    pair_split4(va, &ha, &ra);
+    pair_split4(vb, &hb, &rb);
+    *reinterpret_cast<f16x8 *>(row + pair_hi_col(n, W)) = cat_f16x4(ha, hb);
+    *reinterpret_cast<f16x8 *>(row + pair_lo_col(n, W)) = cat_f16x4(ra, rb);
+}
 #define EPI_PAIR_STORE(v, row, W, n) pair_store4(v, row, W, n)
+#define EPI_PAIR_STORE8(va, vb, row, W, n) epi_pair_store8(va, vb, row, W, n)
 #define EPI_F32_STORE(p, v) (*(p) = (v))
 #endif
+
+// slice statistics of the pair epilogues: a lane holds 8 columns of a row, 4 lanes a 32-column block, 8 lanes the 64-column slice
+__device__ __forceinline__ float quad_sum(float x) {  // every lane of the quad ends with the same bits
+    x += __builtin_amdgcn_update_dpp(0.f, x, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
+    x += __builtin_amdgcn_update_dpp(0.f, x, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
+    return x;
+}
+__device__ __forceinline__ float half_mirror(float x) { return __builtin_amdgcn_update_dpp(0.f, x, 0x141, 0xF, 0xF, true); }  // lane j <- lane 7 - j
+__device__ __forceinline__ float sum8(const f32x4 a, const f32x4 b) { return ((a[0] + a[1]) + (a[2] + a[3])) + ((b[0] + b[1]) + (b[2] + b[3])); }
+__device__ __forceinline__ float sumsq8(const f32x4 a, const f32x4 b, float m) {
+    const float a0 = a[0] - m, a1 = a[1] - m, a2 = a[2] - m, a3 = a[3] - m, b0 = b[0] - m, b1 = b[1] - m, b2 = b[2] - m, b3 = b[3] - m;
+    return ((a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3)) + ((b0 * b0 + b1 * b1) + (b2 * b2 + b3 * b3));
+}
 
 // One structure for the three of them: 4 passes over the wave's 128 rows, each through the wave-private fp32 slab
 // [32 m][64 n] (as EPI_RES32 / EPI_RESLN), so that on read-back a lane owns 4 consecutive columns of a row and global
@@ -446,6 +481,9 @@ __device__ __forceinline__ void epi_pair_store_nt(const f32x4 v, _Float16 *row, 
 //   EPI_S_RESLN  out16 pair [m][n]   = pair(acc' + bias + LayerNorm(residual pair)), + slice statistics (part_out)
 // acc' = acc winv: winv is the inverse of the power of two the weight was stored with (exact; it rides on the row's rstd or in
 // the one fma that adds the residual, so it costs no instruction).
+// Columns per lane on read-back: 8 for the pair-row outputs (16-byte hi and 16-byte lo accesses: 4 lanes write the 64 + 64 bytes of a
+// pair block), 4 for the fp32 rows of QKV (16 lanes write 256 contiguous bytes; with 8 columns a lane's two 16-byte stores would
+// interleave with its neighbours' -- measured +3.5 % on that GEMM).
 template <int EPI>
 __device__ __forceinline__ void gemm256_epilogue_split(const GemmArgs &G, f32x16 (&acc)[2][4], float *smem_f, int m0, int n0,
                                                        int w, int l, float winv) {
@@ -455,25 +493,33 @@ __device__ __forceinline__ void gemm256_epilogue_split(const GemmArgs &G, f32x16
     const int mw0 = m0 + wm * 128, nw0 = n0 + wn * 64;
     float *slab = smem_f + w * 4096;
     constexpr int LS = 68;
-    const int c4 = l & 15;
+    constexpr int CPL = EPI == EPI_S_QKV ? 4 : 8, NV = CPL / 4;  // columns per lane, f32x4 per lane and row
+    constexpr int LPR = 64 / CPL, RPI = 64 / LPR, ITS = 32 / RPI;  // lanes per row, rows per instruction, instructions per pass
+    const int cl = l % LPR, rl_ = l / LPR;
+    const int nc = nw0 + cl * CPL;      // first of this lane's columns
     const float *pb = smem_f + EPB_OFF;
-    const f32x4 v0 = *reinterpret_cast<const f32x4 *>(pb + EPB_VEC + wn * 64 + c4 * 4);        // bias (b' for the folded ones)
-    const f32x4 v1 = *reinterpret_cast<const f32x4 *>(pb + EPB_VEC + 256 + wn * 64 + c4 * 4);  // csum | gamma
-    f32x4 v2 = {0.f, 0.f, 0.f, 0.f};
-    if constexpr (EPI == EPI_S_RESLN) v2 = *reinterpret_cast<const f32x4 *>(pb + EPB_VEC + 512 + wn * 64 + c4 * 4);  // beta
+    const float *vp = pb + EPB_VEC + wn * 64 + cl * CPL;
+    f32x4 v0[NV], v1[NV], v2[NV];       // bias (b' for the folded ones) | csum or gamma | beta
+#pragma unroll
+    for (int h = 0; h < NV; ++h) {
+        v0[h] = *reinterpret_cast<const f32x4 *>(vp + 4 * h);
+        v1[h] = *reinterpret_cast<const f32x4 *>(vp + 256 + 4 * h);
+        v2[h] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (EPI == EPI_S_RESLN) v2[h] = *reinterpret_cast<const f32x4 *>(vp + 512 + 4 * h);
+    }
     const int n_parts = G.N >> 6, slice = nw0 >> 6;
     float vmax = 0.f;  // range guard: running maximum of |what this thread stores| (common.h)
 #pragma unroll
     for (int y = 0; y < 4; ++y) {
-        f16x4 rh[8], rl[8];
-        float mean[8], rstd[8];
+        f16x8 rh[ITS], rl[ITS];
+        float mean[ITS], rstd[ITS];
 #pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const int rr = it * 4 + (l >> 4);
+        for (int it = 0; it < ITS; ++it) {
+            const int rr = it * RPI + rl_;
             if constexpr (EPI == EPI_S_RESLN) {
                 const _Float16 *rp = G.res_hi + (size_t)(mw0 + y * 32 + rr) * G.ldr;
-                rh[it] = *reinterpret_cast<const f16x4 *>(rp + pair_hi_col(nw0 + c4 * 4, G.N));
-                rl[it] = *reinterpret_cast<const f16x4 *>(rp + pair_lo_col(nw0 + c4 * 4, G.N));
+                rh[it] = *reinterpret_cast<const f16x8 *>(rp + pair_hi_col(nc, G.N));
+                rl[it] = *reinterpret_cast<const f16x8 *>(rp + pair_lo_col(nc, G.N));
             }
             mean[it] = pb[EPB_STATS + 2 * (wm * 128 + y * 32 + rr)];
             rstd[it] = pb[EPB_STATS + 2 * (wm * 128 + y * 32 + rr) + 1];
@@ -488,53 +534,53 @@ __device__ __forceinline__ void gemm256_epilogue_split(const GemmArgs &G, f32x16
                     f32x4{a[4 * rq], a[4 * rq + 1], a[4 * rq + 2], a[4 * rq + 3]};
             }
         epi_sync<true>();
-        const size_t row0 = (size_t)(mw0 + y * 32 + (l >> 4));
-        f32x4 vv[8];
+        f32x4 vv[ITS][NV];
 #pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const int rr = it * 4 + (l >> 4);
-            f32x4 v = *reinterpret_cast<const f32x4 *>(slab + rr * LS + c4 * 4);
-            const size_t row = row0 + (size_t)it * 4;
-            if constexpr (EPI == EPI_S_RESLN) {
+        for (int it = 0; it < ITS; ++it) {
+            const int rr = it * RPI + rl_;
+            const size_t row = (size_t)(mw0 + y * 32 + rr);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float a = rstd[it] * v1[e];
-                    const float res = (float)rh[it][e] + (float)rl[it][e] * PAIR_LO_INV;  // exact in fp32: 22 bits
-                    v[e] = __builtin_fmaf(v[e], winv, __builtin_fmaf(res - mean[it], a, v0[e] + v2[e]));
-                }
-                range_track4(v, &vmax);
-                EPI_PAIR_STORE(v, G.out16 + row * G.ldc, G.N, nw0 + c4 * 4);
-                vv[it] = v;
-            } else {
-                const float mr = mean[it] * rstd[it], rw = rstd[it] * winv;  // r (acc winv) = acc (r winv): winv is a power of two
+            for (int h = 0; h < NV; ++h) {
+                f32x4 a = *reinterpret_cast<const f32x4 *>(slab + rr * LS + cl * CPL + 4 * h);
+                if constexpr (EPI == EPI_S_RESLN) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(v[e], rw, __builtin_fmaf(-mr, v1[e], v0[e]));
-                if constexpr (EPI == EPI_S_QKV) {
-                    range_track4(v, &vmax);  // the attention splits K and V into pairs while it stages them
-                    EPI_F32_STORE(reinterpret_cast<f32x4 *>(G.out32 + row * G.ldc + nw0 + c4 * 4), v);
+                    for (int e = 0; e < 4; ++e) {
+                        const float ga = rstd[it] * v1[h][e];
+                        const float ra = (float)rh[it][4 * h + e] + (float)rl[it][4 * h + e] * PAIR_LO_INV;  // exact in fp32: 22 bits
+                        a[e] = __builtin_fmaf(a[e], winv, __builtin_fmaf(ra - mean[it], ga, v0[h][e] + v2[h][e]));
+                    }
                 } else {
+                    const float mr = mean[it] * rstd[it], rw = rstd[it] * winv;  // r (acc winv) = acc (r winv): winv is a power of two
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = gelu_exact(v[e]);
-                    range_track4(v, &vmax);
-                    EPI_PAIR_STORE(v, G.out16 + row * G.ldc, G.N, nw0 + c4 * 4);
+                    for (int e = 0; e < 4; ++e) a[e] = __builtin_fmaf(a[e], rw, __builtin_fmaf(-mr, v1[h][e], v0[h][e]));
+                    if constexpr (EPI == EPI_S_GELU) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) a[e] = gelu_exact(a[e]);
+                    }
                 }
+                range_track4(a, &vmax);  // (QKV: the attention splits K and V into pairs while it stages them)
+                vv[it][h] = a;
             }
+            if constexpr (EPI == EPI_S_QKV) EPI_F32_STORE(reinterpret_cast<f32x4 *>(G.out32 + row * G.ldc + nc), vv[it][0]);
+            else EPI_PAIR_STORE8(vv[it][0], vv[it][NV - 1], G.out16 + row * G.ldc, G.N, nc);
         }
         if constexpr (EPI == EPI_S_RESLN) {
-            float s8[8], q8[8];
+            // (mean, M2) of the 64 columns of every row: lane sums of 8 columns, quad sums (32 columns), the two quads of the row
+            float s4[ITS], q4[ITS];
 #pragma unroll
-            for (int it = 0; it < 8; ++it) s8[it] = row16_sum((vv[it][0] + vv[it][1]) + (vv[it][2] + vv[it][3])) * (1.0f / 64.0f);
-#pragma unroll
-            for (int it = 0; it < 8; ++it) {
-                const float m64 = s8[it];
-                const float d0 = vv[it][0] - m64, d1 = vv[it][1] - m64, d2 = vv[it][2] - m64, d3 = vv[it][3] - m64;
-                q8[it] = row16_sum((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3));
+            for (int it = 0; it < ITS; ++it) {
+                const float s = quad_sum(sum8(vv[it][0], vv[it][NV - 1]));
+                s4[it] = (s + half_mirror(s)) * (1.0f / 64.0f);
             }
-            if (c4 == 0) {
-                float *pp = G.part_out + (row0 * n_parts + slice) * 2;
-                const size_t pstep = (size_t)4 * n_parts * 2;
 #pragma unroll
-                for (int it = 0; it < 8; ++it) *reinterpret_cast<float2 *>(pp + it * pstep) = make_float2(s8[it], q8[it]);
+            for (int it = 0; it < ITS; ++it) {
+                const float q = quad_sum(sumsq8(vv[it][0], vv[it][NV - 1], s4[it]));
+                q4[it] = q + half_mirror(q);
+            }
+            if (cl == 0) {
+#pragma unroll
+                for (int it = 0; it < ITS; ++it)
+                    *reinterpret_cast<float2 *>(G.part_out + ((size_t)(mw0 + y * 32 + it * RPI + rl_) * n_parts + slice) * 2) = make_float2(s4[it], q4[it]);
             }
         }
     }
@@ -546,30 +592,10 @@ __device__ __forceinline__ void gemm256_epilogue_split(const GemmArgs &G, f32x16
 // persistent kernel has left while the next output tile's first K-tiles are in flight in the stage buffers: a wave-private slab of
 // [32 m][32 n] fp32 (row stride 36 floats: the 16-byte writes of 16 lanes fall into 16 different bank quads; 4.5 KiB per wave
 // instead of the 16 KiB slices of the stage buffers the launch-per-tile kernel's epilogue reuses), EIGHT passes (y, x) of 32 rows x 32
-// columns.  A 32-column block is exactly one [hi (32) | lo (32)] block of a pair row (common.h): on read-back 8 lanes cover a row
-// -- 128 contiguous bytes of fp32 (EPI_S_QKV) or the 64 + 64 bytes of one pair block -- 8 rows per instruction.
+// columns.  A 32-column block is exactly one [hi (32) | lo (32)] block of a pair row (common.h): on read-back a row of the pass is
+// 8 lanes x 16 bytes = 128 contiguous bytes of fp32 (EPI_S_QKV) or 4 lanes x (16 + 16) = the 64 + 64 bytes of one pair block.
 // EPI_S_RESLN: the residual pair of pass p + 1 is requested before pass p's slab round trip (one pass of latency hidden per pass);
-// the (mean, M2) of a 64-column slice combine the two passes x = 0, 1 of a row block in the association of the 16-lane reduction
-// above (slice64_sum).
-// sum over the 4 lanes of a quad (every lane of the quad ends with the same bits) / the value of lane 7 - j of the 8-lane group
-__device__ __forceinline__ float quad_sum(float x) {
-    x += __builtin_amdgcn_update_dpp(0.f, x, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
-    x += __builtin_amdgcn_update_dpp(0.f, x, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
-    return x;
-}
-__device__ __forceinline__ float half_mirror(float x) { return __builtin_amdgcn_update_dpp(0.f, x, 0x141, 0xF, 0xF, true); }
-// The 64-column reduction of row16_sum from the two 32-column passes of this epilogue, in row16_sum's OWN association: there the
-// four quads of a DPP row hold column blocks Q0..Q3 of 16 columns and after  row_ror:4, row_ror:8  quad k holds
-// (Qk + Qk-1) + (Qk-2 + Qk-3)  -- the lanes of Q0 and Q2 end with (Q0 + Q3) + (Q1 + Q2), those of Q1 and Q3 with (Q0 + Q1) + (Q2 + Q3),
-// and lane 0 (which stores the statistics) is in Q0.  Here pass x = 0 has Q0 on lanes 0-3 and Q1 on lanes 4-7 of an 8-lane group,
-// pass x = 1 has Q2 | Q3: a = the quad sums of pass 0, b = of pass 1.
-__device__ __forceinline__ float slice64_sum(float a, float b, bool low_quad) {
-    const float ma = half_mirror(a), mb = half_mirror(b);
-    const float lo = (a + mb) + (ma + b);   // lanes 0-3: (Q0 + Q3) + (Q1 + Q2)
-    const float hi = (a + ma) + (b + mb);   // lanes 4-7: (Q1 + Q0) + (Q3 + Q2)
-    return low_quad ? lo : hi;
-}
-
+// the (mean, M2) of a 64-column slice combine the two passes x = 0, 1 of a row block in the association of the reduction above.
 constexpr int EPS_LS = 36;                       // slab row stride (floats)
 constexpr int EPS_SLAB_FLOATS = 32 * EPS_LS;     // 4,608 bytes per wave
 
@@ -581,30 +607,38 @@ __device__ __forceinline__ void gemm256_epilogue_split32(const GemmArgs &G, f32x
     const int wm = w >> 2, wn = w & 3;
     const int mw0 = m0 + wm * 128, nw0 = n0 + wn * 64;
     constexpr int LS = EPS_LS;
-    const int c8 = l & 7, r8 = l >> 3;
+    constexpr int CPL = EPI == EPI_S_QKV ? 4 : 8, NV = CPL / 4;  // columns per lane (gemm256_epilogue_split), f32x4 per lane and row
+    constexpr int LPR = 32 / CPL, RPI = 64 / LPR, ITS = 32 / RPI;  // lanes per row of the pass, rows per instruction, instructions per pass
+    const int cl = l % LPR, rl_ = l / LPR;
     const int n_parts = G.N >> 6, slice = nw0 >> 6;
     float vmax = 0.f;  // range guard (common.h)
-    f16x4 rh[2][4], rl[2][4];  // EPI_S_RESLN: residual pairs of the current and the next pass
+    f16x8 rh[2][ITS], rl[2][ITS];  // EPI_S_RESLN: residual pairs of the current and the next pass
     auto res_load = [&](int p, int buf) {
         const int y = p >> 1, x = p & 1;
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const _Float16 *rp = G.res_hi + (size_t)(mw0 + y * 32 + it * 8 + r8) * G.ldr;
-            rh[buf][it] = *reinterpret_cast<const f16x4 *>(rp + pair_hi_col(nw0 + x * 32 + c8 * 4, G.N));
-            rl[buf][it] = *reinterpret_cast<const f16x4 *>(rp + pair_lo_col(nw0 + x * 32 + c8 * 4, G.N));
+        for (int it = 0; it < ITS; ++it) {
+            const _Float16 *rp = G.res_hi + (size_t)(mw0 + y * 32 + it * RPI + rl_) * G.ldr;
+            rh[buf][it] = *reinterpret_cast<const f16x8 *>(rp + pair_hi_col(nw0 + x * 32 + cl * CPL, G.N));
+            rl[buf][it] = *reinterpret_cast<const f16x8 *>(rp + pair_lo_col(nw0 + x * 32 + cl * CPL, G.N));
         }
     };
     if constexpr (EPI == EPI_S_RESLN) res_load(0, 0);
-    f32x4 keep[4];  // EPI_S_RESLN: the x = 0 values of the pass's four rows (slice statistics need all 64 columns)
+    float s0[ITS];
+    f32x4 keep[ITS][NV];  // EPI_S_RESLN: 32-column sums and values of the x = 0 pass (the slice statistics need all 64 columns)
 #pragma unroll
     for (int p = 0; p < 8; ++p) {
         const int y = p >> 1, x = p & 1;
         if constexpr (EPI == EPI_S_RESLN)
             if (p + 1 < 8) res_load(p + 1, (p + 1) & 1);
-        const f32x4 v0 = *reinterpret_cast<const f32x4 *>(vec + wn * 64 + x * 32 + c8 * 4);        // bias (b' for the folded ones)
-        const f32x4 v1 = *reinterpret_cast<const f32x4 *>(vec + 256 + wn * 64 + x * 32 + c8 * 4);  // csum | gamma
-        f32x4 v2 = {0.f, 0.f, 0.f, 0.f};
-        if constexpr (EPI == EPI_S_RESLN) v2 = *reinterpret_cast<const f32x4 *>(vec + 512 + wn * 64 + x * 32 + c8 * 4);  // beta
+        const float *vp = vec + wn * 64 + x * 32 + cl * CPL;
+        f32x4 v0[NV], v1[NV], v2[NV];  // bias (b' for the folded ones) | csum or gamma | beta
+#pragma unroll
+        for (int h = 0; h < NV; ++h) {
+            v0[h] = *reinterpret_cast<const f32x4 *>(vp + 4 * h);
+            v1[h] = *reinterpret_cast<const f32x4 *>(vp + 256 + 4 * h);
+            v2[h] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if constexpr (EPI == EPI_S_RESLN) v2[h] = *reinterpret_cast<const f32x4 *>(vp + 512 + 4 * h);
+        }
         epi_sync<true>();
 #pragma unroll
         for (int rq = 0; rq < 4; ++rq) {
@@ -612,63 +646,56 @@ __device__ __forceinline__ void gemm256_epilogue_split32(const GemmArgs &G, f32x
             *reinterpret_cast<f32x4 *>(slab + i * LS + 8 * rq + 4 * g) = f32x4{a[4 * rq], a[4 * rq + 1], a[4 * rq + 2], a[4 * rq + 3]};
         }
         epi_sync<true>();
-        f32x4 vv[4];
+        f32x4 vv[ITS][NV];
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int rr = it * 8 + r8;
-            f32x4 v = *reinterpret_cast<const f32x4 *>(slab + rr * LS + c8 * 4);
+        for (int it = 0; it < ITS; ++it) {
+            const int rr = it * RPI + rl_;
             const float mean = stats[2 * (wm * 128 + y * 32 + rr)], rstd = stats[2 * (wm * 128 + y * 32 + rr) + 1];
             const size_t row = (size_t)(mw0 + y * 32 + rr);
-            const int n = nw0 + x * 32 + c8 * 4;
-            if constexpr (EPI == EPI_S_RESLN) {
-                const int b = p & 1;
+            const int n = nw0 + x * 32 + cl * CPL;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float a = rstd * v1[e];
-                    const float res = (float)rh[b][it][e] + (float)rl[b][it][e] * PAIR_LO_INV;  // exact in fp32: 22 bits
-                    v[e] = __builtin_fmaf(v[e], winv, __builtin_fmaf(res - mean, a, v0[e] + v2[e]));
-                }
-                range_track4(v, &vmax);
-                EPI_PAIR_STORE(v, G.out16 + row * G.ldc, G.N, n);
-                vv[it] = v;
-            } else {
-                const float mr = mean * rstd, rw = rstd * winv;  // r (acc winv) = acc (r winv): winv is a power of two
+            for (int h = 0; h < NV; ++h) {
+                f32x4 a = *reinterpret_cast<const f32x4 *>(slab + rr * LS + cl * CPL + 4 * h);
+                if constexpr (EPI == EPI_S_RESLN) {
+                    const int bf = p & 1;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(v[e], rw, __builtin_fmaf(-mr, v1[e], v0[e]));
-                if constexpr (EPI == EPI_S_QKV) {
-                    range_track4(v, &vmax);
-                    EPI_F32_STORE(reinterpret_cast<f32x4 *>(G.out32 + row * G.ldc + n), v);
+                    for (int e = 0; e < 4; ++e) {
+                        const float ga = rstd * v1[h][e];
+                        const float ra = (float)rh[bf][it][4 * h + e] + (float)rl[bf][it][4 * h + e] * PAIR_LO_INV;  // exact in fp32: 22 bits
+                        a[e] = __builtin_fmaf(a[e], winv, __builtin_fmaf(ra - mean, ga, v0[h][e] + v2[h][e]));
+                    }
                 } else {
+                    const float mr = mean * rstd, rw = rstd * winv;  // r (acc winv) = acc (r winv): winv is a power of two
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = gelu_exact(v[e]);
-                    range_track4(v, &vmax);
-                    EPI_PAIR_STORE(v, G.out16 + row * G.ldc, G.N, n);
+                    for (int e = 0; e < 4; ++e) a[e] = __builtin_fmaf(a[e], rw, __builtin_fmaf(-mr, v1[h][e], v0[h][e]));
+                    if constexpr (EPI == EPI_S_GELU) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) a[e] = gelu_exact(a[e]);
+                    }
                 }
+                range_track4(a, &vmax);
+                vv[it][h] = a;
             }
+            if constexpr (EPI == EPI_S_QKV) EPI_F32_STORE(reinterpret_cast<f32x4 *>(G.out32 + row * G.ldc + n), vv[it][0]);
+            else EPI_PAIR_STORE8(vv[it][0], vv[it][NV - 1], G.out16 + row * G.ldc, G.N, n);
         }
         if constexpr (EPI == EPI_S_RESLN) {
+            // slice statistics in the association of gemm256_epilogue_split: lane sums of 8 columns, quad sums = 32 columns (here a pass),
+            // then the two 32-column halves of the slice (here the passes x = 0 and x = 1 of a row block)
             if (x == 0) {
 #pragma unroll
-                for (int it = 0; it < 4; ++it) keep[it] = vv[it];
-            } else {
-                float s4[4], q4[4];
-                const bool lowq = c8 < 4;
-#pragma unroll
-                for (int it = 0; it < 4; ++it)
-                    s4[it] = slice64_sum(quad_sum((keep[it][0] + keep[it][1]) + (keep[it][2] + keep[it][3])),
-                                         quad_sum((vv[it][0] + vv[it][1]) + (vv[it][2] + vv[it][3])), lowq) * (1.0f / 64.0f);
-#pragma unroll
-                for (int it = 0; it < 4; ++it) {
-                    const float m64 = s4[it];
-                    const float a0 = keep[it][0] - m64, a1 = keep[it][1] - m64, a2 = keep[it][2] - m64, a3 = keep[it][3] - m64;
-                    const float d0 = vv[it][0] - m64, d1 = vv[it][1] - m64, d2 = vv[it][2] - m64, d3 = vv[it][3] - m64;
-                    q4[it] = slice64_sum(quad_sum((a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3)), quad_sum((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3)), lowq);
+                for (int it = 0; it < ITS; ++it) {
+                    s0[it] = quad_sum(sum8(vv[it][0], vv[it][NV - 1]));
+                    keep[it][0] = vv[it][0];
+                    keep[it][NV - 1] = vv[it][NV - 1];
                 }
-                if (c8 == 0) {
+            } else {
 #pragma unroll
-                    for (int it = 0; it < 4; ++it)
-                        *reinterpret_cast<float2 *>(G.part_out + ((size_t)(mw0 + y * 32 + it * 8 + r8) * n_parts + slice) * 2) =
-                            make_float2(s4[it], q4[it]);
+                for (int it = 0; it < ITS; ++it) {
+                    const float m64 = (s0[it] + quad_sum(sum8(vv[it][0], vv[it][NV - 1]))) * (1.0f / 64.0f);
+                    const float q64 = quad_sum(sumsq8(keep[it][0], keep[it][NV - 1], m64)) + quad_sum(sumsq8(vv[it][0], vv[it][NV - 1], m64));
+                    if (cl == 0)
+                        *reinterpret_cast<float2 *>(G.part_out + ((size_t)(mw0 + y * 32 + it * RPI + rl_) * n_parts + slice) * 2) = make_float2(m64, q64);
                 }
             }
         }

@@ -303,14 +303,18 @@ __global__ void __launch_bounds__(G256_THREADS, 2) gemm256_split_kernel(const Ge
     GSTAMP(1);
     (void)epb_stats(G, smem_f, tid);
     GSTAMP(2);
+#ifdef ANCE_EPI32_IN_PER_TILE  // diagnosis builds only (make variant NAME=epi32 DEFS=-DANCE_EPI32_IN_PER_TILE): the streaming kernel's 32 x 32-pass epilogue here
+    gemm256_epilogue_split32<EPI>(G, acc, smem_f + w * 4096, smem_f + EPB_OFF + EPB_STATS, smem_f + EPB_OFF + EPB_VEC, m0, n0, w, l, winv);
+#else
     gemm256_epilogue_split<EPI>(G, acc, smem_f, m0, n0, w, l, winv);
+#endif
 #ifdef ANCE_MEASURE
     if (stamps_) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
     GSTAMP(3);
 }
 
-// PERSISTENT, STREAMING form of the split GEMM (round 6; ANCE_GEMM_STREAM=1 -- measured flat, the kernel above stays the product).
+// PERSISTENT, STREAMING form of the split GEMM (round 6): the product's kernel for the QKV and FFN1 GEMMs (ANCE_GEMM_STREAM, below).
 // One workgroup per CU walks its own sequence of output tiles; the K loop of tile i ends as Pipe256T::tiles_streaming -- its last
 // two K-tiles stage K-tile 0 and A0 / B0 / B1 of K-tile 1 of tile i + 1 in the steady-state rhythm -- so tile i's epilogue runs with
 // the next tile's first operand bytes in flight and the next K loop starts where a steady-state K-tile starts: no pipeline fill
@@ -336,10 +340,12 @@ static_assert(5 * EPS_SLAB_FLOATS <= 256 * 24 + 768 && 3 * EPS_SLAB_FLOATS * 4 <
 #define ANCE_STREAM_LOOSE_FIRST 1  // 1: K-tile 0 of a prefetched tile does not wait for the previous epilogue's stores (pipe256.h: tile2); 0: steady-state waits
 #endif
 // vector-memory operations EVERY wave issues between the hand-over's last LDS-DMA and K-tile 0 of the next output tile: the
-// epilogue's stores (gemm256_epilogue_split32: 8 passes x 4 fp32 stores, x 4 x 2 pair stores, RESLN + 64 loads + 16 statistics) and
-// the three LDS-DMAs of the slice partials (eps_issue; the vector DMAs are issued by three waves only and do not count)
+// epilogue's stores (gemm256_epilogue_split32: 8 passes x 2 rows-groups x 2 16-byte stores = 32 for the fp32 rows of QKV and for the
+// hi | lo halves of a pair row alike; RESLN + 32 residual loads, its statistics stores are issued by some lanes only but by every
+// wave: not counted, the count is a lower bound) and the three LDS-DMAs of the slice partials (eps_issue; the vector DMAs are issued
+// by three waves only and do not count)
 template <int EPI>
-constexpr int eps_foreign_ops() { return (EPI == EPI_S_QKV ? 32 : EPI == EPI_S_GELU ? 64 : 144) + 3; }
+constexpr int eps_foreign_ops() { return (EPI == EPI_S_RESLN ? 64 : 32) + 3; }
 
 template <int EPI_>
 __device__ __forceinline__ void eps_issue(const GemmArgs &G, float *smem_f, int m0, int n0, int w, int l) {
@@ -358,6 +364,19 @@ __device__ __forceinline__ void eps_issue(const GemmArgs &G, float *smem_f, int 
     } else {
         if (w == 1) __builtin_amdgcn_global_load_lds((glb_t *)(G.csum + n0 + l * 4), (lds_t *)(smem_f + EPS_VEC + 256), 16, 0, 0);
     }
+}
+
+// the kernel's GemmArgs re-read from the kernarg segment (first argument) behind an opaque pointer: see the call site
+__device__ __forceinline__ GemmArgs kernarg_reload(const GemmArgs &G) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef const __attribute__((address_space(4))) GemmArgs *kernarg_ptr_t;
+    kernarg_ptr_t gp = (kernarg_ptr_t)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(gp));
+    (void)G;
+    return *gp;
+#else
+    return G;
+#endif
 }
 
 // workgroup barrier that does NOT drain the vector-memory counter (the next tile's LDS-DMAs and this tile's stores stay in flight)
@@ -434,10 +453,7 @@ __global__ void __launch_bounds__(G256_THREADS, 2) gemm256_split_stream_kernel(c
         const int tf = (w << 6) | lf;
         // (the same for the kernel arguments: ~50 SGPRs of pointers and strides that only the epilogue uses would otherwise stay live
         // across the K loop -- re-read from the kernarg segment per tile instead)
-        typedef const __attribute__((address_space(4))) GemmArgs *kernarg_ptr_t;
-        kernarg_ptr_t gp = (kernarg_ptr_t)__builtin_amdgcn_kernarg_segment_ptr();
-        asm volatile("" : "+s"(gp));
-        const GemmArgs Ge = *gp;
+        const GemmArgs Ge = kernarg_reload(G);
         // (mean, rstd) of the tile's tokens from their slice partials (in R since before this K loop), published by one barrier;
         // after it R belongs to the slabs
         if (tf < 256) {
@@ -539,15 +555,16 @@ unsigned long long *g_gemm_stamps_host = nullptr;
 int g_gemm_stamps_epi = EPI_RESLN;  // which epilogue's launches are stamped (ance_debug_gemm_stamps_epi)
 #endif
 
-// ANCE_GEMM_STREAM=1: the persistent streaming split GEMM (measured flat against the launch-per-tile kernel and rejected:
-// DESIGN_REJECTED.md round 6; read once per process, ance_reload_env re-reads it)
+// ANCE_GEMM_STREAM: 1 (default) = the persistent streaming kernel for the QKV and FFN1 GEMMs (same-box A/B: -1.3 % / -1.7 % per
+// launch), the launch-per-tile kernel for the two RESLN GEMMs (streaming them measured +1.0 % / +1.5 %: DESIGN_REJECTED.md round 6);
+// 0 = launch-per-tile everywhere, 2 = streaming everywhere (A/B).  Read once per process, ance_reload_env re-reads it.
 int g_gemm_stream = -1;
-bool gemm_stream_enabled() {
+int gemm_stream_mode() {
     if (g_gemm_stream < 0) {
         const char *e = getenv("ANCE_GEMM_STREAM");
-        g_gemm_stream = (e && e[0] == '1') ? 1 : 0;
+        g_gemm_stream = (e && e[0] == '0') ? 0 : (e && e[0] == '2') ? 2 : 1;
     }
-    return g_gemm_stream == 1;
+    return g_gemm_stream;
 }
 int device_cu_count() {
     static int cus[64] = {0};
@@ -602,7 +619,7 @@ int launch256(int epi, const GemmArgs &G, hipStream_t st) {
             return check_launch("gemm256 attr");
         attr_mark(&attr_done[ai]);
     }
-    if (!ABLATE && epi >= EPI_S_QKV && gemm_stream_enabled() && G.K >= 96 && (uint64_t)G.M * (uint64_t)G.lda * 2u < (1ull << 31) &&
+    if (!ABLATE && epi >= EPI_S_QKV && (gemm_stream_mode() == 2 || (gemm_stream_mode() == 1 && epi != EPI_S_RESLN)) && G.K >= 96 && (uint64_t)G.M * (uint64_t)G.lda * 2u < (1ull << 31) &&
         (uint64_t)G.N * (uint64_t)G.ldb * 2u < (1ull << 31)
 #ifdef ANCE_MEASURE
         && !(epi == g_gemm_stamps_epi && g_gemm_stamps_host)

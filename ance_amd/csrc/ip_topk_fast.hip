@@ -540,6 +540,29 @@ struct FastSrc {
         if constexpr (TYPE < 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rq, dst, 16, voff[TYPE][J], so, 0, 0);
         else __builtin_amdgcn_raw_ptr_buffer_load_lds(nxt ? rx1 : rx0, dst, 16, voff[TYPE][J], so, 0, 0);
     }
+    // Round 6 (pipe256.h: PRECOMPUTE): the K offsets of the eight LDS-DMAs of a K-tile and the corpus descriptor of K-tile t + 2 are
+    // computed ONCE per K-tile, in the read half-phase -- the compare / select / shift chains (and the four s_cselect of the descriptor)
+    // used to sit in front of each DMA, between the MFMAs, fenced there by the schedule's sched_barriers: ~25 scalar instructions per
+    // K-tile in the matrix pipe's shadow.
+#ifdef ANCE_FAST_NO_PRECOMPUTE  // A/B builds only (make variant NAME=noprep DEFS=-DANCE_FAST_NO_PRECOMPUTE): the form of rounds 2-5
+    static constexpr bool PRECOMPUTE = false;
+#else
+    static constexpr bool PRECOMPUTE = true;
+#endif
+    int so_1, so_2;                // K offset (bytes) of K-tile t + 1 (A-half1) and of K-tile t + 2 (A-half0, B-half0, B-half1)
+    __amdgpu_buffer_rsrc_t rx_2;   // corpus descriptor of K-tile t + 2
+    __device__ __forceinline__ void prepare(int t) {
+        const int t1 = t + 1, t2 = t + 2;
+        so_1 = (t1 >= NK ? t1 - NK : t1) * (FK * 2);
+        so_2 = (t2 >= NK ? t2 - NK : t2) * (FK * 2);
+        rx_2 = t2 >= NK ? rx1 : rx0;
+    }
+    template <int TYPE, int J>
+    __device__ __forceinline__ void issue_pre(pipe_lds_t *dst) const {
+        if constexpr (TYPE == 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rq, dst, 16, voff[TYPE][J], so_1, 0, 0);
+        else if constexpr (TYPE == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rq, dst, 16, voff[TYPE][J], so_2, 0, 0);
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rx_2, dst, 16, voff[TYPE][J], so_2, 0, 0);
+    }
 };
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t tile_rsrc(const _Float16 *base, uint32_t first_row, uint32_t n_rows, int d) {

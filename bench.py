@@ -276,7 +276,8 @@ ARITHMETIC_OF = {
              "7e-6 at 12 layers against the reference's own class)",
     "fp16": "fp16 MFMA operands, fp32 accumulation, LayerNorm folded into the GEMMs, residual stream as fp16 (hi, lo) pairs (stated 5e-3)",
     "fp32": "fp32 operands on v_mfma_f32_32x32x2_f32, exact erf GELU, fp32 softmax (the reference's arithmetic; the audit path)"}
-KERNEL_OF_SPLIT = {"gemm_ffn1": "gemm256_split_kernel<9>", "gemm_qk": "gemm256_split_kernel<8>",
+# (round 6: QKV and FFN1 run the persistent streaming kernel, the two RESLN GEMMs the launch-per-tile kernel: csrc/gemm256_f16.hip)
+KERNEL_OF_SPLIT = {"gemm_ffn1": "gemm256_split_stream_kernel<9>", "gemm_qk": "gemm256_split_stream_kernel<8>",
                    "gemm_attn_out": "gemm256_split_kernel<10>", "gemm_ffn2": "gemm256_split_kernel<10>"}
 KERNEL_OF_FP32 = {"gemm_ffn1": "gemm32_kernel<1>", "gemm_qk": "gemm32_kernel<0>", "gemm_attn_out": "gemm32_kernel<2>",
                   "gemm_ffn2": "gemm32_kernel<2>"}

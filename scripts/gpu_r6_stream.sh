@@ -6,6 +6,7 @@ set -u
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
 export TMPDIR=/tmp
+echo "== tr16 probe"; tools/tr16_probe > gpurun_out/tr16_probe.txt 2>&1; echo "probe rc=$?"; tail -2 gpurun_out/tr16_probe.txt
 timeout 600 python -m pytest tests/test_gpu_gemm.py -q -x -p no:cacheprovider -k "streaming or split" > gpurun_out/t_gemm.log 2>&1; echo "gemm rc=$?"; tail -5 gpurun_out/t_gemm.log
 timeout 900 python -m pytest tests/test_gpu_encoder.py -q -x -p no:cacheprovider -k "split or golden or default or large_micro" > gpurun_out/t_enc.log 2>&1; echo "enc rc=$?"; tail -5 gpurun_out/t_enc.log
 rm -f gpurun_out/ab_stream.jsonl

@@ -125,7 +125,7 @@ if len(sys.argv) > 2:
         return {"block_passages": 4096, "dispatches": tot["FETCH_SIZE_dispatches"], "fetch_bytes_x2": 2.0 * tot["FETCH_SIZE"],
                 "write_bytes": tot["WRITE_SIZE"], "hbm_bytes_per_step": b, "ms_per_step_untraced_single_stream": ms,
                 "hbm_gbs_rocprof": b / (ms * 1e-3) / 1e9, "bytes_per_passage": b / 4096.0, "passages_per_sec": pps,
-                "round": os.environ.get("ANCE_ROUND", "r05"), "encoder_precision": line.get("encoder_precision"),
+                "round": os.environ.get("ANCE_ROUND", "r06"), "encoder_precision": line.get("encoder_precision"),
                 "note": "sum over every encoder dispatch of one step (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; "
                         "FETCH_SIZE doubled per MI355X_MICROARCH.md) / the untraced time of the same step; the algorithmic minimum is "
                         "4 + 4 L + 3072 bytes per passage -- the rest is activation round trips between the kernels of a layer"}
@@ -140,7 +140,9 @@ if len(sys.argv) > 2:
     for leg, cat, needle in (("encode", "gemm_ffn1", "gemm256_f16_desc_kernel<6"), ("encode", "gemm_qk", "gemm256_f16_desc_kernel<5"),
                              ("encode", "gemm_res", "gemm256_f16_desc_kernel<4"), ("encode", "gemm_vt", "gemm256_f16_desc_kernel<7"),
                              ("encode", "attention", "attention_kernel"),
-                             ("encode_split", "gemm_ffn1", "gemm256_split_kernel<9"), ("encode_split", "gemm_qk", "gemm256_split_kernel<8"),
+                             # (round 6: QKV and FFN1 run the persistent streaming kernel)
+                             ("encode_split", "gemm_ffn1", "gemm256_split_stream_kernel<9"), ("encode_split", "gemm_qk", "gemm256_split_stream_kernel<8"),
+                             ("encode_split", "gemm_ffn1_per_tile", "gemm256_split_kernel<9"), ("encode_split", "gemm_qk_per_tile", "gemm256_split_kernel<8"),
                              ("encode_split", "gemm_res", "gemm256_split_kernel<10"), ("encode_split", "attention", "attention_split_kernel"),
                              ("search", "ip_topk_fast", "ip_topk_fast_kernel<false, false>"), ("search", "ip_topk_rescore", "rescore_kernel"),
                              ("search", "ip_topk_scan", "ip_topk_scan_kernel")):
@@ -151,7 +153,7 @@ if len(sys.argv) > 2:
         out.setdefault(leg, {})[cat] = {"cycles": cycles(leg, needle), "l2_hit_rate": l2_hit(leg, needle),
                                         "kernel_trace_avg_ns": avg_ns, "kernel_trace_dispatches": n_disp,
                                         "hbm_bytes_per_launch": 2.0 * fe + wr, "fetch_bytes_x2": 2.0 * fe, "write_bytes": wr,
-                                        "round": os.environ.get("ANCE_ROUND", "r05"),
+                                        "round": os.environ.get("ANCE_ROUND", "r06"),
                                         "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / TCC_HIT,MISS / cycles (separate passes) on the bench.py leg "
                                                 "itself (scripts/gpu_pmc.sh); FETCH_SIZE doubled per MI355X_MICROARCH.md (wide reads on gfx950)"}
     with open(sys.argv[2], "w") as f:

@@ -235,7 +235,7 @@ def _split_raw(epi, M, N, K, seed, stream, monkeypatch):
     """One launch of the split GEMM through its test hook, with the persistent streaming kernel (the product's) or the
     launch-per-tile kernel (ANCE_GEMM_STREAM=0); returns the raw output buffers."""
     from ance_amd import _lib
-    monkeypatch.setenv("ANCE_GEMM_STREAM", "1" if stream else "0")
+    monkeypatch.setenv("ANCE_GEMM_STREAM", "2" if stream else "0")  # 2: every epilogue on the streaming kernel (the product streams QKV and FFN1)
     _lib.reload_env()
     L = _lib.lib()
     g = torch.Generator(device="cuda").manual_seed(seed)

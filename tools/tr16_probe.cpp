@@ -17,7 +17,29 @@ __global__ void probe(short *out) {
     for (int j = 0; j < 4; ++j) out[l * 4 + j] = v[j];
 }
 
+// v_permlane32_swap_b32 x, y: x[l + 32] <-> y[l] (the split attention trades register quads between the two halves of a wave with it)
+__global__ void probe_swap(int *out) {
+    const int l = threadIdx.x;
+    int x = l, y = 100 + l;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(x), "+v"(y));
+    out[l] = x;
+    out[64 + l] = y;
+}
+
 int main() {
+    {
+        int *ds, hs[128];
+        if (hipMalloc(&ds, sizeof(hs)) != hipSuccess) return 2;
+        hipLaunchKernelGGL(probe_swap, dim3(1), dim3(64), 0, 0, ds);
+        if (hipMemcpy(hs, ds, sizeof(hs), hipMemcpyDeviceToHost) != hipSuccess) return 2;
+        int bad = 0;
+        for (int l = 0; l < 64; ++l) {
+            const int want_x = l < 32 ? l : 100 + (l - 32), want_y = l < 32 ? l + 32 : 100 + l;
+            bad += hs[l] != want_x || hs[64 + l] != want_y;
+        }
+        printf("v_permlane32_swap_b32: %s (x[l + 32] <-> y[l]), %d mismatches\n", bad ? "DIFFERENT RULE" : "rule confirmed", bad);
+        if (bad) return 1;
+    }
     short *d, h[256];
     if (hipMalloc(&d, sizeof(h)) != hipSuccess) return 2;
     hipLaunchKernelGGL(probe, dim3(1), dim3(64), 0, 0, d);
