@@ -277,7 +277,8 @@ __global__ void __launch_bounds__(64 * NW, 3) attention_kernel(const AttnArgs A)
 // with gfx950's LDS transpose read (ds_read_b64_tr_b16: every lane gives the address of 4 contiguous halves, within each group of
 // 16 lanes the 16 x 4 block arrives transposed: out[l][j] = in[16 (l / 16) + 4 j + (l % 16) / 4][l % 4], tools/tr16_probe.cpp).  The
 // first form transposed while staging: sixteen 2-byte LDS writes per 8 dims of a key, four-way bank-conflicted -- 44 % of the kernel's
-// LDS-array cycles were conflict cycles (profiles/r05_sq_counters_split_gemms.json).  Same fragment values, same MFMAs: bit-identical.
+// LDS-array cycles were conflict cycles (profiles/r05_sq_counters_split_gemms.json).  Same fragment values, same MFMAs: bit-identical
+// to that form (checked with both compiled in, commit abaa8b9: tests/test_gpu_encoder.py::test_split_attention_transpose_reads_change_no_bit).
 constexpr int VS = HD + 8;  // row stride of V in LDS (halves): 144 bytes = 36 banks -- the four rows a 16-lane group reads fall into disjoint bank octets
 typedef short s16x4_t __attribute__((ext_vector_type(4)));
 typedef s16x4_t __attribute__((address_space(3))) lds_s16x4_t;
@@ -294,7 +295,7 @@ __device__ __forceinline__ void permlane32_swap(float &x, float &y) {
     asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(x), "+v"(y));
 }
 
-template <int NW, bool TR>
+template <int NW>
 __global__ void __launch_bounds__(64 * NW, 2) attention_split_kernel(const float *qkv, _Float16 *ctx_pair, const int4 *desc, int n_heads,
                                                                      int cls_only, int kchunk) {
     extern __shared__ __attribute__((aligned(16))) float smem_f[];
@@ -306,11 +307,10 @@ __global__ void __launch_bounds__(64 * NW, 2) attention_split_kernel(const float
     // keys are staged kc keys at a time (kchunk = the launch's LDS budget, a multiple of 32): all of them at once for the
     // sequences that fit (every sequence of config 2), 256 at a time for longer ones -- the online softmax does not care
     const int kc = Tk < kchunk ? Tk : kchunk;
-    const int vld = kc + 4;
     _Float16 *Kh = reinterpret_cast<_Float16 *>(smem_f);  // [kc][64] chunk-swizzled
     _Float16 *Kl = Kh + (size_t)kc * HD;
-    _Float16 *Vh = Kl + (size_t)kc * HD;                  // TR: [kc][VS] row-major; else [64][vld] transposed
-    _Float16 *Vl = Vh + (TR ? (size_t)kc * VS : (size_t)HD * vld);
+    _Float16 *Vh = Kl + (size_t)kc * HD;                  // [kc][VS] row-major
+    _Float16 *Vl = Vh + (size_t)kc * VS;
     const int tid = threadIdx.x;
     const int w = tid >> 6, l = tid & 63, g = l >> 5, i = l & 31;
     constexpr int NT = 64 * NW;
@@ -353,25 +353,15 @@ __global__ void __launch_bounds__(64 * NW, 2) attention_split_kernel(const float
                 }
                 *reinterpret_cast<f16x8 *>(Kh + kl_ * HD + kswz(kl_, ch) * 8) = kh;
                 *reinterpret_cast<f16x8 *>(Kl + kl_ * HD + kswz(kl_, ch) * 8) = kl;
-                if constexpr (TR) {
-                    f16x8 vh, vl;
+                f16x8 vh, vl;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        vh[j] = b0[j]; vh[4 + j] = b1[j];
-                        vl[j] = (_Float16)((v0[j] - (float)b0[j]) * SC);
-                        vl[4 + j] = (_Float16)((v1[j] - (float)b1[j]) * SC);
-                    }
-                    *reinterpret_cast<f16x8 *>(Vh + kl_ * VS + ch * 8) = vh;
-                    *reinterpret_cast<f16x8 *>(Vl + kl_ * VS + ch * 8) = vl;
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        Vh[(ch * 8 + j) * vld + kl_] = b0[j];
-                        Vh[(ch * 8 + 4 + j) * vld + kl_] = b1[j];
-                        Vl[(ch * 8 + j) * vld + kl_] = (_Float16)((v0[j] - (float)b0[j]) * SC);
-                        Vl[(ch * 8 + 4 + j) * vld + kl_] = (_Float16)((v1[j] - (float)b1[j]) * SC);
-                    }
+                for (int j = 0; j < 4; ++j) {
+                    vh[j] = b0[j]; vh[4 + j] = b1[j];
+                    vl[j] = (_Float16)((v0[j] - (float)b0[j]) * SC);
+                    vl[4 + j] = (_Float16)((v1[j] - (float)b1[j]) * SC);
                 }
+                *reinterpret_cast<f16x8 *>(Vh + kl_ * VS + ch * 8) = vh;
+                *reinterpret_cast<f16x8 *>(Vl + kl_ * VS + ch * 8) = vl;
             }
         }
     };
@@ -466,18 +456,10 @@ __global__ void __launch_bounds__(64 * NW, 2) attention_split_kernel(const float
                     const int kcol = kb * 32 + 16 * uu + 4 * g;
                     // V^T fragment of head dims row .. (lane i), keys kcol + {0..3, 8..11}
                     auto vfrag = [&](const _Float16 *V, int row) {
-                        f16x4 a, b;
-                        if constexpr (TR) {
-                            // lane q of a 16-lane group points at key kcol + q / 4, dims (row - i) + 16 (lane / 16 % 2) + 4 (q % 4) .. + 3
-                            const int q = l & 15;
-                            const _Float16 *vp = V + (kcol + (q >> 2)) * VS + (row - i) + 16 * ((l >> 4) & 1) + 4 * (q & 3);
-                            a = lds_read_tr16(vp);
-                            b = lds_read_tr16(vp + 8 * VS);
-                        } else {
-                            const _Float16 *vp = V + row * vld + kcol;
-                            a = *reinterpret_cast<const f16x4 *>(vp);
-                            b = *reinterpret_cast<const f16x4 *>(vp + 8);
-                        }
+                        // lane q of a 16-lane group points at key kcol + q / 4, dims (row - i) + 16 (lane / 16 % 2) + 4 (q % 4) .. + 3
+                        const int q = l & 15;
+                        const _Float16 *vp = V + (kcol + (q >> 2)) * VS + (row - i) + 16 * ((l >> 4) & 1) + 4 * (q & 3);
+                        const f16x4 a = lds_read_tr16(vp), b = lds_read_tr16(vp + 8 * VS);
                         return f16x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
                     };
                     const f16x8 v0h = vfrag(Vh, i), v1h = vfrag(Vh, i + 32), v0l = vfrag(Vl, i), v1l = vfrag(Vl, i + 32);
@@ -493,7 +475,7 @@ __global__ void __launch_bounds__(64 * NW, 2) attention_split_kernel(const float
         if (!active) continue;
         const float l_tot = l_run + __shfl_xor(l_run, 32);
         const float inv = 1.0f / l_tot;
-        if constexpr (TR) {
+        {
             // C-layout: a lane owns 4 consecutive head dims per register quad (8 rq + 4 g + j); lanes l and l + 32 (g = 0 / 1) own the two
             // halves of every 8-dim group.  v_permlane32_swap trades them so that lane g = 0 ends with dims 16 k .. 16 k + 7 and lane
             // g = 1 with 16 k + 8 .. + 15: 16-byte hi and lo stores instead of 8-byte ones -- half as many vector-memory instructions
@@ -528,21 +510,6 @@ __global__ void __launch_bounds__(64 * NW, 2) attention_split_kernel(const float
                     }
                 }
             }
-        } else if (qb0 + i < q_end) {
-            const size_t orow = cls_only ? (size_t)s : (size_t)(tok0 + qb0 + i);
-            _Float16 *orp = ctx_pair + orow * (size_t)(2 * n_heads * HD);  // pair row (common.h) of n_heads * 64 columns
-#pragma unroll
-            for (int db = 0; db < 2; ++db) {
-                const f32x16 &om = db == 0 ? om0 : om1;
-                const f32x16 &oc = db == 0 ? oc0 : oc1;
-#pragma unroll
-                for (int rq = 0; rq < 4; ++rq) {
-                    f32x4 v;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = __builtin_fmaf(oc[4 * rq + j], SI, om[4 * rq + j]) * inv;
-                    pair_store4(v, orp, n_heads * HD, h * HD + db * 32 + 8 * rq + 4 * g);
-                }
-            }
         }
     }
 }
@@ -551,15 +518,14 @@ __global__ void __launch_bounds__(64 * NW, 2) attention_split_kernel(const float
 
 size_t attention_split_lds_bytes(int max_seq_len) {
     const int Tk = (max_seq_len + 31) & ~31;
-    const size_t v_tr = (size_t)2 * Tk * VS * 2, v_t = (size_t)2 * HD * (Tk + 4) * 2;
-    return (size_t)2 * Tk * HD * 2 + (v_tr > v_t ? v_tr : v_t);
+    return (size_t)2 * Tk * HD * 2 + (size_t)2 * Tk * VS * 2;  // K hi | lo' [Tk][64], V hi | lo' [Tk][VS]
 }
 
 // qkv [T, 3 n_heads 64] fp32 -> ctx_pair [T or n_seq, 2 n_heads 64] fp16 pair rows; any sequence length (keys staged 256 at a time).
 // Measured and rejected (round 4): the sequences of <= 64 tokens in a second launch of 2-wave / 33 KB workgroups (4 per CU, no idle
 // waves): 179.6 + 66.3 us against 242.1 us in one launch.
 int launch_attention_split(const float *qkv, _Float16 *ctx_pair, const int4 *desc, int n_seq, int n_heads, int max_seq_len,
-                           int cls_only, hipStream_t st, bool tr) {
+                           int cls_only, hipStream_t st) {
     if (n_seq <= 0) return ANCE_OK;
     const int Tk = (max_seq_len + 31) & ~31;
     const int kchunk = Tk <= 256 ? Tk : 256;  // keys staged at a time: 66 KB at 128 (two workgroups per CU), 132 KB at 256
@@ -569,19 +535,13 @@ int launch_attention_split(const float *qkv, _Float16 *ctx_pair, const int4 *des
     static size_t attr_set[64] = {0};
     const bool tracked = dev >= 0 && dev < 64;
     if (!tracked || lds > __atomic_load_n(&attr_set[dev], __ATOMIC_ACQUIRE)) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(attention_split_kernel<4, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void *>(attention_split_kernel<4, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(attention_split_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds) != hipSuccess)
             return check_launch("attention_split attr");
         if (tracked) __atomic_store_n(&attr_set[dev], lds, __ATOMIC_RELEASE);
     }
-    if (tr)  // (else: V transposed while staging, the form before round 6 -- ANCE_ATTN_TR=0 when the handle is created; A/B)
-        hipLaunchKernelGGL((attention_split_kernel<4, true>), dim3((unsigned)n_seq * n_heads), dim3(256), lds, st, qkv, ctx_pair, desc, n_heads,
-                           cls_only, kchunk);
-    else
-        hipLaunchKernelGGL((attention_split_kernel<4, false>), dim3((unsigned)n_seq * n_heads), dim3(256), lds, st, qkv, ctx_pair, desc, n_heads,
-                           cls_only, kchunk);
+    hipLaunchKernelGGL((attention_split_kernel<4>), dim3((unsigned)n_seq * n_heads), dim3(256), lds, st, qkv, ctx_pair, desc, n_heads,
+                       cls_only, kchunk);
     return ANCE_OK;
 }
 

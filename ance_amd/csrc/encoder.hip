@@ -779,7 +779,6 @@ struct AnceEncoder {
     bool n_split;   // FFN1 with the N-split tile order (ANCE_GEMM_NSPLIT=0 disables)
     bool split_attn; // split mode: attention on the matrix cores (ANCE_SPLIT_ATTN=0: fp32 vector-unit kernel)
     bool attn_coal; // attention Q / output rows through LDS slabs (ANCE_ATTN_COAL=0: per-lane accesses)
-    bool attn_tr;   // split attention: V row-major in LDS + LDS transpose reads (ANCE_ATTN_TR=0: transposed while staging)
 };
 
 namespace {
@@ -1086,7 +1085,7 @@ int encode_impl(AnceEncoder *e, const int32_t *base, int64_t ld, const int32_t *
                         ProfScope ps(PC_ATTN, st);
                         if (tail && S_pad > S)  // rows S..S_pad of the compact attention output feed the GEMM tile: keep them finite
                             (void)hipMemsetAsync(ctxp + (size_t)S * HP, 0, (size_t)(S_pad - S) * HP * sizeof(_Float16), st);
-                        rc = e->split_attn ? launch_attention_split(LN.qkv32, ctxp, LN.desc, S, D.n_heads, maxlen, tail ? 1 : 0, st, e->attn_tr)
+                        rc = e->split_attn ? launch_attention_split(LN.qkv32, ctxp, LN.desc, S, D.n_heads, maxlen, tail ? 1 : 0, st)
                                            : ANCE_E_INVALID;
                         if (rc == ANCE_E_INVALID)  // ANCE_SPLIT_ATTN=0: the fp32 vector-unit kernel (A/B)
                             rc = launch_attention32(LN.qkv32, nullptr, LN.seq_off, S, D.n_heads, st, ctxp, tail ? 1 : 0);
@@ -1369,8 +1368,6 @@ extern "C" int ance_encoder_create(const AnceEncoderDesc *desc, const void *cons
         e->n_split = !(nsp && nsp[0] == '0');
         const char *sa = getenv("ANCE_SPLIT_ATTN");
         e->split_attn = !(sa && sa[0] == '0');
-        const char *tr = getenv("ANCE_ATTN_TR");
-        e->attn_tr = !(tr && tr[0] == '0');
         const char *ns = getenv("ANCE_ENCODER_STREAMS");
         e->n_lanes = (ns && ns[0] >= '1' && ns[0] <= '0' + MAX_LANES) ? ns[0] - '0' : 2;
     }

@@ -587,15 +587,15 @@ __device__ __forceinline__ void gemm256_epilogue_split(const GemmArgs &G, f32x16
     range_report(vmax, G.range_faults);
 }
 
-// ---- epilogues of the STREAMING (persistent) split GEMM ------------------------------------------------------------------
-// The same three epilogues, bit for bit (tests/test_gpu_gemm.py compares the two kernels with array_equal), in the LDS the
-// persistent kernel has left while the next output tile's first K-tiles are in flight in the stage buffers: a wave-private slab of
-// [32 m][32 n] fp32 (row stride 36 floats: the 16-byte writes of 16 lanes fall into 16 different bank quads; 4.5 KiB per wave
-// instead of the 16 KiB slices of the stage buffers the launch-per-tile kernel's epilogue reuses), EIGHT passes (y, x) of 32 rows x 32
-// columns.  A 32-column block is exactly one [hi (32) | lo (32)] block of a pair row (common.h): on read-back a row of the pass is
+// ---- epilogues of the STREAMING (persistent) split GEMM: EPI_S_QKV and EPI_S_GELU -----------------------------------------
+// The same arithmetic, bit for bit (tests/test_gpu_gemm.py compares the two kernels with array_equal), in the LDS the persistent
+// kernel has left while the next output tile's first K-tiles are in flight in the stage buffers: a wave-private slab of [32 m][32 n]
+// fp32 (row stride 36 floats: the 16-byte writes of 16 lanes fall into 16 different bank quads; 4.5 KiB per wave instead of the
+// 16 KiB slices of the stage buffers the launch-per-tile kernel's epilogue reuses), EIGHT passes (y, x) of 32 rows x 32 columns.
+// A 32-column block is exactly one [hi (32) | lo (32)] block of a pair row (common.h): on read-back a row of the pass is
 // 8 lanes x 16 bytes = 128 contiguous bytes of fp32 (EPI_S_QKV) or 4 lanes x (16 + 16) = the 64 + 64 bytes of one pair block.
-// EPI_S_RESLN: the residual pair of pass p + 1 is requested before pass p's slab round trip (one pass of latency hidden per pass);
-// the (mean, M2) of a 64-column slice combine the two passes x = 0, 1 of a row block in the association of the reduction above.
+// (EPI_S_RESLN in this form -- residual rows requested a pass ahead, slice statistics combined over the passes x = 0, 1 -- measured
+// 1.6-3.4 us per tile slower than the 32 x 64 form: commit abaa8b9, DESIGN_REJECTED.md round 6.)
 constexpr int EPS_LS = 36;                       // slab row stride (floats)
 constexpr int EPS_SLAB_FLOATS = 32 * EPS_LS;     // 4,608 bytes per wave
 
@@ -603,6 +603,7 @@ template <int EPI>
 __device__ __forceinline__ void gemm256_epilogue_split32(const GemmArgs &G, f32x16 (&acc)[2][4], float *slab, const float *stats,
                                                          const float *vec, int m0, int n0, int w, int l, float winv) {
 #pragma clang fp contract(off)
+    static_assert(EPI == EPI_S_QKV || EPI == EPI_S_GELU, "the RESLN GEMMs run the launch-per-tile kernel (DESIGN_REJECTED.md round 6)");
     const int g = l >> 5, i = l & 31;
     const int wm = w >> 2, wn = w & 3;
     const int mw0 = m0 + wm * 128, nw0 = n0 + wn * 64;
@@ -610,34 +611,16 @@ __device__ __forceinline__ void gemm256_epilogue_split32(const GemmArgs &G, f32x
     constexpr int CPL = EPI == EPI_S_QKV ? 4 : 8, NV = CPL / 4;  // columns per lane (gemm256_epilogue_split), f32x4 per lane and row
     constexpr int LPR = 32 / CPL, RPI = 64 / LPR, ITS = 32 / RPI;  // lanes per row of the pass, rows per instruction, instructions per pass
     const int cl = l % LPR, rl_ = l / LPR;
-    const int n_parts = G.N >> 6, slice = nw0 >> 6;
     float vmax = 0.f;  // range guard (common.h)
-    f16x8 rh[2][ITS], rl[2][ITS];  // EPI_S_RESLN: residual pairs of the current and the next pass
-    auto res_load = [&](int p, int buf) {
-        const int y = p >> 1, x = p & 1;
-#pragma unroll
-        for (int it = 0; it < ITS; ++it) {
-            const _Float16 *rp = G.res_hi + (size_t)(mw0 + y * 32 + it * RPI + rl_) * G.ldr;
-            rh[buf][it] = *reinterpret_cast<const f16x8 *>(rp + pair_hi_col(nw0 + x * 32 + cl * CPL, G.N));
-            rl[buf][it] = *reinterpret_cast<const f16x8 *>(rp + pair_lo_col(nw0 + x * 32 + cl * CPL, G.N));
-        }
-    };
-    if constexpr (EPI == EPI_S_RESLN) res_load(0, 0);
-    float s0[ITS];
-    f32x4 keep[ITS][NV];  // EPI_S_RESLN: 32-column sums and values of the x = 0 pass (the slice statistics need all 64 columns)
 #pragma unroll
     for (int p = 0; p < 8; ++p) {
         const int y = p >> 1, x = p & 1;
-        if constexpr (EPI == EPI_S_RESLN)
-            if (p + 1 < 8) res_load(p + 1, (p + 1) & 1);
         const float *vp = vec + wn * 64 + x * 32 + cl * CPL;
-        f32x4 v0[NV], v1[NV], v2[NV];  // bias (b' for the folded ones) | csum or gamma | beta
+        f32x4 v0[NV], v1[NV];  // b' | csum
 #pragma unroll
         for (int h = 0; h < NV; ++h) {
             v0[h] = *reinterpret_cast<const f32x4 *>(vp + 4 * h);
             v1[h] = *reinterpret_cast<const f32x4 *>(vp + 256 + 4 * h);
-            v2[h] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if constexpr (EPI == EPI_S_RESLN) v2[h] = *reinterpret_cast<const f32x4 *>(vp + 512 + 4 * h);
         }
         epi_sync<true>();
 #pragma unroll
@@ -646,58 +629,28 @@ __device__ __forceinline__ void gemm256_epilogue_split32(const GemmArgs &G, f32x
             *reinterpret_cast<f32x4 *>(slab + i * LS + 8 * rq + 4 * g) = f32x4{a[4 * rq], a[4 * rq + 1], a[4 * rq + 2], a[4 * rq + 3]};
         }
         epi_sync<true>();
-        f32x4 vv[ITS][NV];
 #pragma unroll
         for (int it = 0; it < ITS; ++it) {
             const int rr = it * RPI + rl_;
             const float mean = stats[2 * (wm * 128 + y * 32 + rr)], rstd = stats[2 * (wm * 128 + y * 32 + rr) + 1];
+            const float mr = mean * rstd, rw = rstd * winv;  // r (acc winv) = acc (r winv): winv is a power of two
             const size_t row = (size_t)(mw0 + y * 32 + rr);
             const int n = nw0 + x * 32 + cl * CPL;
+            f32x4 vv[NV];
 #pragma unroll
             for (int h = 0; h < NV; ++h) {
                 f32x4 a = *reinterpret_cast<const f32x4 *>(slab + rr * LS + cl * CPL + 4 * h);
-                if constexpr (EPI == EPI_S_RESLN) {
-                    const int bf = p & 1;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float ga = rstd * v1[h][e];
-                        const float ra = (float)rh[bf][it][4 * h + e] + (float)rl[bf][it][4 * h + e] * PAIR_LO_INV;  // exact in fp32: 22 bits
-                        a[e] = __builtin_fmaf(a[e], winv, __builtin_fmaf(ra - mean, ga, v0[h][e] + v2[h][e]));
-                    }
-                } else {
-                    const float mr = mean * rstd, rw = rstd * winv;  // r (acc winv) = acc (r winv): winv is a power of two
+                for (int e = 0; e < 4; ++e) a[e] = __builtin_fmaf(a[e], rw, __builtin_fmaf(-mr, v1[h][e], v0[h][e]));
+                if constexpr (EPI == EPI_S_GELU) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) a[e] = __builtin_fmaf(a[e], rw, __builtin_fmaf(-mr, v1[h][e], v0[h][e]));
-                    if constexpr (EPI == EPI_S_GELU) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) a[e] = gelu_exact(a[e]);
-                    }
+                    for (int e = 0; e < 4; ++e) a[e] = gelu_exact(a[e]);
                 }
                 range_track4(a, &vmax);
-                vv[it][h] = a;
+                vv[h] = a;
             }
-            if constexpr (EPI == EPI_S_QKV) EPI_F32_STORE(reinterpret_cast<f32x4 *>(G.out32 + row * G.ldc + n), vv[it][0]);
-            else EPI_PAIR_STORE8(vv[it][0], vv[it][NV - 1], G.out16 + row * G.ldc, G.N, n);
-        }
-        if constexpr (EPI == EPI_S_RESLN) {
-            // slice statistics in the association of gemm256_epilogue_split: lane sums of 8 columns, quad sums = 32 columns (here a pass),
-            // then the two 32-column halves of the slice (here the passes x = 0 and x = 1 of a row block)
-            if (x == 0) {
-#pragma unroll
-                for (int it = 0; it < ITS; ++it) {
-                    s0[it] = quad_sum(sum8(vv[it][0], vv[it][NV - 1]));
-                    keep[it][0] = vv[it][0];
-                    keep[it][NV - 1] = vv[it][NV - 1];
-                }
-            } else {
-#pragma unroll
-                for (int it = 0; it < ITS; ++it) {
-                    const float m64 = (s0[it] + quad_sum(sum8(vv[it][0], vv[it][NV - 1]))) * (1.0f / 64.0f);
-                    const float q64 = quad_sum(sumsq8(keep[it][0], keep[it][NV - 1], m64)) + quad_sum(sumsq8(vv[it][0], vv[it][NV - 1], m64));
-                    if (cl == 0)
-                        *reinterpret_cast<float2 *>(G.part_out + ((size_t)(mw0 + y * 32 + it * RPI + rl_) * n_parts + slice) * 2) = make_float2(m64, q64);
-                }
-            }
+            if constexpr (EPI == EPI_S_QKV) EPI_F32_STORE(reinterpret_cast<f32x4 *>(G.out32 + row * G.ldc + n), vv[0]);
+            else EPI_PAIR_STORE8(vv[0], vv[NV - 1], G.out16 + row * G.ldc, G.N, n);
         }
     }
     range_report(vmax, G.range_faults);

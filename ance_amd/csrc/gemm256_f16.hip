@@ -303,11 +303,7 @@ __global__ void __launch_bounds__(G256_THREADS, 2) gemm256_split_kernel(const Ge
     GSTAMP(1);
     (void)epb_stats(G, smem_f, tid);
     GSTAMP(2);
-#ifdef ANCE_EPI32_IN_PER_TILE  // diagnosis builds only (make variant NAME=epi32 DEFS=-DANCE_EPI32_IN_PER_TILE): the streaming kernel's 32 x 32-pass epilogue here
-    gemm256_epilogue_split32<EPI>(G, acc, smem_f + w * 4096, smem_f + EPB_OFF + EPB_STATS, smem_f + EPB_OFF + EPB_VEC, m0, n0, w, l, winv);
-#else
     gemm256_epilogue_split<EPI>(G, acc, smem_f, m0, n0, w, l, winv);
-#endif
 #ifdef ANCE_MEASURE
     if (stamps_) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
@@ -340,12 +336,10 @@ static_assert(5 * EPS_SLAB_FLOATS <= 256 * 24 + 768 && 3 * EPS_SLAB_FLOATS * 4 <
 #define ANCE_STREAM_LOOSE_FIRST 1  // 1: K-tile 0 of a prefetched tile does not wait for the previous epilogue's stores (pipe256.h: tile2); 0: steady-state waits
 #endif
 // vector-memory operations EVERY wave issues between the hand-over's last LDS-DMA and K-tile 0 of the next output tile: the
-// epilogue's stores (gemm256_epilogue_split32: 8 passes x 2 rows-groups x 2 16-byte stores = 32 for the fp32 rows of QKV and for the
-// hi | lo halves of a pair row alike; RESLN + 32 residual loads, its statistics stores are issued by some lanes only but by every
-// wave: not counted, the count is a lower bound) and the three LDS-DMAs of the slice partials (eps_issue; the vector DMAs are issued
-// by three waves only and do not count)
-template <int EPI>
-constexpr int eps_foreign_ops() { return (EPI == EPI_S_RESLN ? 64 : 32) + 3; }
+// epilogue's stores (gemm256_epilogue_split32: 8 passes x 4 16-byte stores of fp32 rows for QKV, 8 x 2 x (hi + lo) for the pair rows of
+// GELU: 32 either way) and the three LDS-DMAs of the slice partials (eps_issue; the vector DMAs are issued by two waves only and do not
+// count)
+constexpr int EPS_FOREIGN_OPS = 32 + 3;
 
 template <int EPI_>
 __device__ __forceinline__ void eps_issue(const GemmArgs &G, float *smem_f, int m0, int n0, int w, int l) {
@@ -358,12 +352,7 @@ __device__ __forceinline__ void eps_issue(const GemmArgs &G, float *smem_f, int 
         __builtin_amdgcn_global_load_lds((glb_t *)(psrc + piece * 256 + l * 4), (lds_t *)(smem_f + EPS_R + piece * 256), 16, 0, 0);
     }
     if (w == 0) __builtin_amdgcn_global_load_lds((glb_t *)(G.bias + n0 + l * 4), (lds_t *)(smem_f + EPS_VEC), 16, 0, 0);
-    if (EPI_ == EPI_S_RESLN) {
-        if (w == 1) __builtin_amdgcn_global_load_lds((glb_t *)(G.res_gamma + n0 + l * 4), (lds_t *)(smem_f + EPS_VEC + 256), 16, 0, 0);
-        if (w == 2) __builtin_amdgcn_global_load_lds((glb_t *)(G.res_beta + n0 + l * 4), (lds_t *)(smem_f + EPS_VEC + 512), 16, 0, 0);
-    } else {
-        if (w == 1) __builtin_amdgcn_global_load_lds((glb_t *)(G.csum + n0 + l * 4), (lds_t *)(smem_f + EPS_VEC + 256), 16, 0, 0);
-    }
+    if (w == 1) __builtin_amdgcn_global_load_lds((glb_t *)(G.csum + n0 + l * 4), (lds_t *)(smem_f + EPS_VEC + 256), 16, 0, 0);
 }
 
 // the kernel's GemmArgs re-read from the kernarg segment (first argument) behind an opaque pointer: see the call site
@@ -440,7 +429,7 @@ __global__ void __launch_bounds__(G256_THREADS, 2) gemm256_split_stream_kernel(c
             P.S.a_nxt = (uint32_t)mtn * 256u * (uint32_t)G.lda * 2u;
             P.S.b_nxt = (uint32_t)ntn * 256u * (uint32_t)G.ldb * 2u;
         }
-        constexpr int F = ANCE_STREAM_LOOSE_FIRST ? eps_foreign_ops<EPI>() : 0;
+        constexpr int F = ANCE_STREAM_LOOSE_FIRST ? EPS_FOREIGN_OPS : 0;
         constexpr int VM0F = 6 + F > 63 ? 63 : 6 + F, VM1F = 2 + F > 63 ? 63 : 2 + F;
         // (the first tile of the workgroup comes from prologue_landed: nothing in flight, the loose waits of its K-tile 0 are trivially enough)
         if (have_n) P.template tiles_streaming<VM0F, VM1F>(NK, acc); else P.template tiles_final<VM0F, VM1F>(NK, acc);
@@ -555,14 +544,14 @@ unsigned long long *g_gemm_stamps_host = nullptr;
 int g_gemm_stamps_epi = EPI_RESLN;  // which epilogue's launches are stamped (ance_debug_gemm_stamps_epi)
 #endif
 
-// ANCE_GEMM_STREAM: 1 (default) = the persistent streaming kernel for the QKV and FFN1 GEMMs (same-box A/B: -1.3 % / -1.7 % per
-// launch), the launch-per-tile kernel for the two RESLN GEMMs (streaming them measured +1.0 % / +1.5 %: DESIGN_REJECTED.md round 6);
-// 0 = launch-per-tile everywhere, 2 = streaming everywhere (A/B).  Read once per process, ance_reload_env re-reads it.
+// ANCE_GEMM_STREAM: 1 (default) = the persistent streaming kernel for the QKV and FFN1 GEMMs (same-box A/Bs: -0.6 .. -1.3 % and
+// -1.7 .. -3.0 % per launch), the launch-per-tile kernel for the two RESLN GEMMs (streaming them measured +1.0 % / +1.5 %:
+// DESIGN_REJECTED.md round 6); 0 = launch-per-tile everywhere (A/B).  Read once per process, ance_reload_env re-reads it.
 int g_gemm_stream = -1;
 int gemm_stream_mode() {
     if (g_gemm_stream < 0) {
         const char *e = getenv("ANCE_GEMM_STREAM");
-        g_gemm_stream = (e && e[0] == '0') ? 0 : (e && e[0] == '2') ? 2 : 1;
+        g_gemm_stream = (e && e[0] == '0') ? 0 : 1;
     }
     return g_gemm_stream;
 }
@@ -619,16 +608,14 @@ int launch256(int epi, const GemmArgs &G, hipStream_t st) {
             return check_launch("gemm256 attr");
         attr_mark(&attr_done[ai]);
     }
-    if (!ABLATE && epi >= EPI_S_QKV && (gemm_stream_mode() == 2 || (gemm_stream_mode() == 1 && epi != EPI_S_RESLN)) && G.K >= 96 && (uint64_t)G.M * (uint64_t)G.lda * 2u < (1ull << 31) &&
+    if (!ABLATE && (epi == EPI_S_QKV || epi == EPI_S_GELU) && gemm_stream_mode() == 1 && G.K >= 96 && (uint64_t)G.M * (uint64_t)G.lda * 2u < (1ull << 31) &&
         (uint64_t)G.N * (uint64_t)G.ldb * 2u < (1ull << 31)
 #ifdef ANCE_MEASURE
         && !(epi == g_gemm_stamps_epi && g_gemm_stamps_host)
 #endif
     ) {
-        void (*ks)(const GemmArgs, int) = epi == EPI_S_QKV    ? gemm256_split_stream_kernel<EPI_S_QKV>
-                                          : epi == EPI_S_GELU ? gemm256_split_stream_kernel<EPI_S_GELU>
-                                                              : gemm256_split_stream_kernel<EPI_S_RESLN>;
-        static unsigned long long sattr_done[3] = {0, 0, 0};
+        void (*ks)(const GemmArgs, int) = epi == EPI_S_QKV ? gemm256_split_stream_kernel<EPI_S_QKV> : gemm256_split_stream_kernel<EPI_S_GELU>;
+        static unsigned long long sattr_done[2] = {0, 0};
         if (attr_needed(&sattr_done[epi - EPI_S_QKV])) {
             if (hipFuncSetAttribute(reinterpret_cast<const void *>(ks), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GS_LDS_BYTES) != hipSuccess)
                 return check_launch("gemm256 stream attr");

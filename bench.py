@@ -956,7 +956,7 @@ def main():
         except Exception as e:
             errors["cpu_baseline"] = repr(e)
     try:  # measured by tests/test_gpu_retrieval.py on an MI355X (fp16-operand encoder vs the fp32 reference arithmetic)
-        src = next(n for n in ("r06_retrieval_agreement.json", "r05_retrieval_agreement.json", "r04_retrieval_agreement.json")
+        src = next(n for n in ("r06_retrieval_agreement.json", "r05_retrieval_agreement.json")
                    if os.path.exists(os.path.join(ROOT, "profiles", n)))
         with open(os.path.join(ROOT, "profiles", src)) as f:
             ra = json.load(f)

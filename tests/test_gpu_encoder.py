@@ -703,29 +703,3 @@ def test_precision_is_chosen_by_the_descriptor_not_by_the_environment(monkeypatc
     assert Encoder(sd, ARCH_ROBERTA, "roberta.", True, precision="split", **kw).precision == "split"
     assert Encoder(sd, ARCH_ROBERTA, "roberta.", True, precision="fp16", **kw).precision == "fp16"
     assert os.environ["ANCE_ENCODER_PRECISE"] == "1" and "ANCE_ENCODER_SPLIT" not in os.environ
-
-
-def test_split_attention_transpose_reads_change_no_bit(monkeypatch):
-    """Round 6: the split attention keeps V row-major in LDS and reads its V^T fragments with gfx950's LDS transpose read
-    (ds_read_b64_tr_b16) instead of transposing with 2-byte LDS writes while staging.  Same fragment values, same MFMAs: the
-    embeddings must be bit-identical to the previous form (ANCE_ATTN_TR=0), for sequences of 1 .. 512 tokens (one staging chunk up
-    to 256 keys, two beyond), ragged last key blocks, and the CLS-only last layer."""
-    from ance_amd.encoder import ARCH_ROBERTA, Encoder
-    from oracle import encoder_ref, synth
-    sd = encoder_ref.random_state_dict(seed=81, n_layers=2, ln_jitter=0.1)
-    rng = np.random.default_rng(82)
-    lens = np.array([1, 2, 31, 32, 33, 64, 65, 96, 97, 127, 128, 129, 255, 256, 257, 300, 384, 511, 512, 7, 100, 200], dtype=np.int32)
-    ids = synth.make_records(rng, len(lens), 512, lens.astype(np.int64))
-    ids_d, lens_d = torch.from_numpy(ids).cuda(), torch.from_numpy(lens).cuda()
-    outs = {}
-    for tr in ("1", "0"):
-        monkeypatch.setenv("ANCE_ATTN_TR", tr)
-        enc = Encoder(sd, ARCH_ROBERTA, "roberta.", True, max_seq_len=512, max_tokens=4096, precision="split")
-        outs[tr] = enc.encode_ids(ids_d, lens_d, h_lens=lens)
-        enc.check_range(sync=True)
-        del enc
-    assert torch.isfinite(outs["1"]).all()
-    assert torch.equal(outs["1"], outs["0"])
-    with torch.no_grad():
-        want = encoder_ref.rdot_nll_ln_emb(sd, torch.from_numpy(ids), encoder_ref.mask_from_lengths(lens, 512), n_layers=2).numpy()
-    assert float(np.abs(outs["1"].cpu().numpy() - want).max()) <= 2e-5

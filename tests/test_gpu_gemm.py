@@ -235,7 +235,7 @@ def _split_raw(epi, M, N, K, seed, stream, monkeypatch):
     """One launch of the split GEMM through its test hook, with the persistent streaming kernel (the product's) or the
     launch-per-tile kernel (ANCE_GEMM_STREAM=0); returns the raw output buffers."""
     from ance_amd import _lib
-    monkeypatch.setenv("ANCE_GEMM_STREAM", "2" if stream else "0")  # 2: every epilogue on the streaming kernel (the product streams QKV and FFN1)
+    monkeypatch.setenv("ANCE_GEMM_STREAM", "1" if stream else "0")
     _lib.reload_env()
     L = _lib.lib()
     g = torch.Generator(device="cuda").manual_seed(seed)
@@ -258,13 +258,13 @@ def _split_raw(epi, M, N, K, seed, stream, monkeypatch):
 
 
 @pytest.mark.parametrize("epi,shape", [(8, (256, 256, 128)), (8, (8192, 2304, 768)), (8, (16640, 2304, 768)), (9, (16384, 3072, 768)),
-                                       (9, (512, 3072, 768)), (10, (32768, 768, 768)), (10, (33024, 768, 3072)), (10, (256, 768, 128))])
+                                       (9, (512, 3072, 768)), (9, (33024, 3072, 768)), (8, (1024, 768, 3072))])
 def test_streaming_split_gemm_equals_the_launch_per_tile_kernel(epi, shape, monkeypatch):
-    """Round 6: the persistent split GEMM (one workgroup per CU walking its output tiles, the next tile's first K-tiles staged
-    under the current epilogue, 32 x 32 epilogue passes in what LDS is left) against the launch-per-tile kernel it replaces:
-    same K order, same epilogue arithmetic, same reduction trees -- every output bit and every slice statistic identical, on
-    shapes with one tile per workgroup, with 2-3 tiles per workgroup, with a ragged last round, and with K = 128 / 768 / 3,072
-    (4 / 24 / 96 K-tiles)."""
+    """Round 6: the persistent split GEMM of the QKV and FFN1 projections (one workgroup per CU walking its output tiles, the next
+    tile's first K-tiles staged under the current epilogue, 32 x 32 epilogue passes in what LDS is left) against the
+    launch-per-tile kernel (ANCE_GEMM_STREAM=0; what the two RESLN GEMMs still run): same K order, same epilogue arithmetic --
+    every output bit identical, on shapes with one tile per workgroup, with 2-6 tiles per workgroup, with a ragged last round,
+    and with K = 128 / 768 / 3,072 (4 / 24 / 96 K-tiles)."""
     from ance_amd import _lib
     M, N, K = shape
     try:
@@ -276,5 +276,3 @@ def test_streaming_split_gemm_equals_the_launch_per_tile_kernel(epi, shape, monk
     assert bool(torch.isfinite(a.float()).all())
     assert torch.equal(a.view(torch.int16) if a.dtype == torch.float16 else a.view(torch.int32),
                        b.view(torch.int16) if b.dtype == torch.float16 else b.view(torch.int32)), (epi, shape)
-    if epi == 10:
-        assert torch.equal(pa.view(torch.int32), pb.view(torch.int32)), "slice statistics differ"

@@ -274,9 +274,9 @@ def replay_persistent(nk, n_out, f_actual, f_claimed, extra_ops_group1=1):
 
 @pytest.mark.parametrize("nk", [4, 6, 8, 24])
 @pytest.mark.parametrize("n_out", [1, 2, 3])
-@pytest.mark.parametrize("f", [0, 35, 67])
+@pytest.mark.parametrize("f", [0, 35])
 def test_persistent_gemm_hand_over(nk, n_out, f):
-    """f = the foreign operations of gemm256_f16.hip: eps_foreign_ops (QKV and GELU 32 + 3, RESLN 64 + 3); 0 = the
+    """f = the foreign operations of gemm256_f16.hip: EPS_FOREIGN_OPS (32 stores + 3 LDS-DMAs for QKV and GELU alike); 0 = the
     steady-state waits on K-tile 0 (ANCE_STREAM_LOOSE_FIRST=0: correct whatever the epilogue issues)."""
     replay_persistent(nk, n_out, f_actual=f, f_claimed=f)
     replay_persistent(nk, n_out, f_actual=f + 20, f_claimed=f)   # an epilogue that issues MORE than claimed only waits longer
