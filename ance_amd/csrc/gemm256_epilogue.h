@@ -420,6 +420,31 @@ __device__ __forceinline__ float gelu_exact(float x) {
     return x * (x >= 0.0f ? 1.0f - e : e);
 }
 
+// Four at a time on the PACKED fp32 pipe (round 6): v_pk_fma_f32 runs two IEEE fmas per issue slot, and the GELU epilogue is bound by
+// its vector instructions (9 of its ~21 per element are the Horner steps: they were v_fmaak_f32, one element each, because the
+// coefficients were literals).  The coefficients come from constant memory here (scalar registers, as kGeluQ above), the steps are
+// element-wise fmas on float2 -- the same operations in the same order: bit-identical to gelu_exact.
+__constant__ float kGeluExactQ[10] = {GELU_Q[0], GELU_Q[1], GELU_Q[2], GELU_Q[3], GELU_Q[4], GELU_Q[5], GELU_Q[6], GELU_Q[7], GELU_Q[8], GELU_Q[9]};
+__device__ __forceinline__ f32x4 gelu_exact4(const f32x4 x) {
+#pragma clang fp contract(off)
+#ifdef ANCE_GELU_ERFF
+    return f32x4{gelu_exact(x[0]), gelu_exact(x[1]), gelu_exact(x[2]), gelu_exact(x[3])};
+#endif
+    f32x4 out;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const f32x2 x2 = {x[2 * p], x[2 * p + 1]};
+        const f32x2 z = __builtin_elementwise_min(__builtin_elementwise_abs(x2) * 0.70710678118654752440f, f32x2{6.6f, 6.6f});
+        f32x2 q = {kGeluExactQ[9], kGeluExactQ[9]};
+#pragma unroll
+        for (int k = 8; k >= 0; --k) q = __builtin_elementwise_fma(q, z, f32x2{kGeluExactQ[k], kGeluExactQ[k]});
+        const float e0 = __builtin_amdgcn_exp2f(q[0]), e1 = __builtin_amdgcn_exp2f(q[1]);
+        out[2 * p] = x2[0] * (x2[0] >= 0.0f ? 1.0f - e0 : e0);
+        out[2 * p + 1] = x2[1] * (x2[1] >= 0.0f ? 1.0f - e1 : e1);
+    }
+    return out;
+}
+
 // Output stores of the split epilogues are NON-TEMPORAL: the outputs of a launch (0.6-1.6 GB) are consumed by the next kernel and
 // only pass through the 4 MB L2s on their way out, where they evict the operand panels the main loops re-read.  Same-box A/B
 // (profiles/r05_ab_nt_store.jsonl, three alternations): FFN1 -0.7 %, the attention that follows the QKV GEMM -2.5 %, step +0.3 %.
@@ -553,10 +578,7 @@ __device__ __forceinline__ void gemm256_epilogue_split(const GemmArgs &G, f32x16
                     const float mr = mean[it] * rstd[it], rw = rstd[it] * winv;  // r (acc winv) = acc (r winv): winv is a power of two
 #pragma unroll
                     for (int e = 0; e < 4; ++e) a[e] = __builtin_fmaf(a[e], rw, __builtin_fmaf(-mr, v1[h][e], v0[h][e]));
-                    if constexpr (EPI == EPI_S_GELU) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) a[e] = gelu_exact(a[e]);
-                    }
+                    if constexpr (EPI == EPI_S_GELU) a = gelu_exact4(a);
                 }
                 range_track4(a, &vmax);  // (QKV: the attention splits K and V into pairs while it stages them)
                 vv[it][h] = a;
@@ -577,11 +599,13 @@ __device__ __forceinline__ void gemm256_epilogue_split(const GemmArgs &G, f32x16
                 const float q = quad_sum(sumsq8(vv[it][0], vv[it][NV - 1], s4[it]));
                 q4[it] = q + half_mirror(q);
             }
-            if (cl == 0) {
-#pragma unroll
-                for (int it = 0; it < ITS; ++it)
-                    *reinterpret_cast<float2 *>(G.part_out + ((size_t)(mw0 + y * 32 + it * RPI + rl_) * n_parts + slice) * 2) = make_float2(s4[it], q4[it]);
-            }
+            // every lane of a row holds the row's (s, q) of all ITS row groups: lane cl < ITS stores group cl -- ONE store instruction
+            // for the 32 rows of the pass instead of ITS (the epilogue is bound by its vector-memory instruction count)
+            static_assert(ITS == 4 && LPR >= 4, "one lane per row group");
+            const float ss = cl == 0 ? s4[0] : cl == 1 ? s4[1] : cl == 2 ? s4[2] : s4[3];
+            const float qq = cl == 0 ? q4[0] : cl == 1 ? q4[1] : cl == 2 ? q4[2] : q4[3];
+            if (cl < ITS)
+                *reinterpret_cast<float2 *>(G.part_out + ((size_t)(mw0 + y * 32 + cl * RPI + rl_) * n_parts + slice) * 2) = make_float2(ss, qq);
         }
     }
     range_report(vmax, G.range_faults);
@@ -642,10 +666,7 @@ __device__ __forceinline__ void gemm256_epilogue_split32(const GemmArgs &G, f32x
                 f32x4 a = *reinterpret_cast<const f32x4 *>(slab + rr * LS + cl * CPL + 4 * h);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) a[e] = __builtin_fmaf(a[e], rw, __builtin_fmaf(-mr, v1[h][e], v0[h][e]));
-                if constexpr (EPI == EPI_S_GELU) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) a[e] = gelu_exact(a[e]);
-                }
+                if constexpr (EPI == EPI_S_GELU) a = gelu_exact4(a);
                 range_track4(a, &vmax);
                 vv[h] = a;
             }

@@ -37,7 +37,7 @@ done
 # kernel of the leg, a 4,096-passage block so that a counter pass (~500 dispatches) finishes, the same block timed untraced
 if [[ " ${PMC_LEGS:-search encode_split} " == *" encode_split "* ]]; then
   export ANCE_ENCODER_STREAMS=1
-  EA="python bench.py --skip-search --no-cpu-baseline --skip-precise --skip-slice --encode-block 4096 --steps 1 --warmup 1"
+  EA="python bench.py --skip-search --no-cpu-baseline --skip-precise --skip-slice --skip-other-configs --encode-block 4096 --steps 1 --warmup 1"
   echo "== untraced step, 4,096-passage block"
   timeout 300 $EA > gpurun_out/pmc/encode_all_plain.json 2> gpurun_out/pmc/encode_all_plain.err; echo "rc=$?"
   for c in FETCH_SIZE WRITE_SIZE; do
