@@ -26,7 +26,44 @@ __global__ void probe_swap(int *out) {
     out[64 + l] = y;
 }
 
+// v_fma_mix_f32 with an f16 operand taken from the low / high half of a packed register: v - (float)hi in one instruction (pair_split4)
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+__global__ void probe_mix(const float *in, float *out_mix, float *out_ref, int n) {
+    const int l = blockIdx.x * blockDim.x + threadIdx.x;
+    if (2 * l + 1 >= n) return;
+    const float v0 = in[2 * l], v1 = in[2 * l + 1];
+    f16x2_t h = {(_Float16)v0, (_Float16)v1};
+    asm volatile("" : "+v"(h));
+    const unsigned hp = __builtin_bit_cast(unsigned, h);
+    float d0, d1;
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(d0) : "v"(hp), "v"(-1.0f), "v"(v0));
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d1) : "v"(hp), "v"(-1.0f), "v"(v1));
+    out_mix[2 * l] = d0; out_mix[2 * l + 1] = d1;
+    out_ref[2 * l] = v0 - (float)h[0]; out_ref[2 * l + 1] = v1 - (float)h[1];
+}
+
 int main() {
+    {
+        const int n = 1 << 20;
+        float *din, *dm, *dr;
+        float *hin = new float[n], *hm = new float[n], *hr = new float[n];
+        unsigned long long st = 88172645463325252ull;
+        for (int j = 0; j < n; ++j) {
+            st ^= st << 13; st ^= st >> 7; st ^= st << 17;
+            // magnitudes from 2^-30 (hi and lo subnormal or zero) to 2^15, both signs
+            const int e = (int)((st >> 40) % 46) - 30;
+            const float m = 1.0f + (float)((st >> 8) & 0xFFFFFF) / 16777216.0f;
+            hin[j] = ((st & 1) ? -1.0f : 1.0f) * m * __builtin_ldexpf(1.0f, e);
+        }
+        if (hipMalloc(&din, n * 4) != hipSuccess || hipMalloc(&dm, n * 4) != hipSuccess || hipMalloc(&dr, n * 4) != hipSuccess) return 2;
+        (void)hipMemcpy(din, hin, n * 4, hipMemcpyHostToDevice);
+        hipLaunchKernelGGL(probe_mix, dim3(n / 2 / 256), dim3(256), 0, 0, din, dm, dr, n);
+        if (hipMemcpy(hm, dm, n * 4, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(hr, dr, n * 4, hipMemcpyDeviceToHost) != hipSuccess) return 2;
+        int bad = 0;
+        for (int j = 0; j < n; ++j) bad += __builtin_memcmp(&hm[j], &hr[j], 4) != 0;
+        printf("v_fma_mix_f32 (f16 half * -1 + v) against v - (float)hi on %d values of magnitude 2^-30 .. 2^15: %d mismatches\n", n, bad);
+        if (bad) return 1;
+    }
     {
         int *ds, hs[128];
         if (hipMalloc(&ds, sizeof(hs)) != hipSuccess) return 2;
