@@ -282,16 +282,13 @@ __global__ void __launch_bounds__(64 * NW, 3) attention_kernel(const AttnArgs A)
 // Row stride of V in LDS (halves) and where dims d .. d + 7 of key `key` sit in the row.  ds_read_b64_tr_b16 is serviced in two groups
 // of 32 lanes over 64 banks (MI355X_MICROARCH.md, LDS): a group here reads 4 keys x 32 dims = 4 x 16 banks.  With 128-byte rows
 // (32 banks) keys k and k + 2 start on the same bank; the first form of this layout padded the rows to 144 bytes (36 banks), which
-// still overlaps keys k and k + 2 on half of their banks -- every transpose read cost two LDS cycles per group instead of one.  Now:
-// unpadded rows, the two 64-byte halves of a row trade places when bit 1 of the key is set -- keys k .. k + 3 of one group fall on
-// banks 0-15 | 32-47 | 16-31 | 48-63.
-#if defined(ANCE_ATTN_V_PAD)  // the padded form, for the A/B of scripts/gpu_r6_attn_phases.sh
-constexpr int VS = HD + 8;
-__device__ __forceinline__ int vswz(int key, int d) { return d; }
-#else
+// still overlaps keys k and k + 2 on half of their banks -- every transpose read cost two LDS cycles per group instead of one
+// (0.22 conflict cycles per LDS-active cycle).  Now: unpadded rows, the two 64-byte halves of a row trade places when bit 1 of the key
+// is set -- keys k .. k + 3 of one group fall on banks 0-15 | 32-47 | 16-31 | 48-63: SQ_LDS_BANK_CONFLICT = 0 for the whole kernel,
+// 22 % fewer LDS-active cycles (profiles/r06_attention_lds_counters.json; the padded form: commit fff5260, ANCE_ATTN_V_PAD).  The
+// kernel's time does not move (the LDS wait is 0.8 % of a wave's cycles): it is bound by its HBM traffic, see DESIGN.md 3.6.
 constexpr int VS = HD;
 __device__ __forceinline__ int vswz(int key, int d) { return d ^ (((key >> 1) & 1) << 5); }
-#endif
 typedef short s16x4_t __attribute__((ext_vector_type(4)));
 typedef s16x4_t __attribute__((address_space(3))) lds_s16x4_t;
 __device__ __forceinline__ f16x4 lds_read_tr16(const _Float16 *p) {
@@ -365,18 +362,24 @@ __global__ void __launch_bounds__(64 * NW, 2) attention_split_kernel(const float
                 const int e = e0 + it * NT;
                 if (e >= kc * 8) break;
                 const int kl_ = e >> 3, ch = e & 7;
-                // (hi, lo') of 8 K and 8 V elements: v - hi by v_fma_mix_f32 (common.h: pair_split4_scaled)
-                f16x4 a0, a1, b0, b1, c0, c1, d0, d1;
-                pair_split4_scaled(kv[it][0], SC, &a0, &c0);
-                pair_split4_scaled(kv[it][1], SC, &a1, &c1);
-                pair_split4_scaled(kv[it][2], SC, &b0, &d0);
-                pair_split4_scaled(kv[it][3], SC, &b1, &d1);
-                const f16x8 kh = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
-                const f16x8 kl = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
-                const f16x8 vh = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
-                const f16x8 vl = {d0[0], d0[1], d0[2], d0[3], d1[0], d1[1], d1[2], d1[3]};
+                const f32x4 k0v = kv[it][0], k1v = kv[it][1], v0 = kv[it][2], v1 = kv[it][3];
+                const f16x4 a0 = cvt_f16x4_pinned(k0v), a1 = cvt_f16x4_pinned(k1v), b0 = cvt_f16x4_pinned(v0), b1 = cvt_f16x4_pinned(v1);
+                f16x8 kh, kl;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    kh[j] = a0[j]; kh[4 + j] = a1[j];
+                    kl[j] = (_Float16)((k0v[j] - (float)a0[j]) * SC);
+                    kl[4 + j] = (_Float16)((k1v[j] - (float)a1[j]) * SC);
+                }
                 *reinterpret_cast<f16x8 *>(Kh + kl_ * HD + kswz(kl_, ch) * 8) = kh;
                 *reinterpret_cast<f16x8 *>(Kl + kl_ * HD + kswz(kl_, ch) * 8) = kl;
+                f16x8 vh, vl;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    vh[j] = b0[j]; vh[4 + j] = b1[j];
+                    vl[j] = (_Float16)((v0[j] - (float)b0[j]) * SC);
+                    vl[4 + j] = (_Float16)((v1[j] - (float)b1[j]) * SC);
+                }
                 *reinterpret_cast<f16x8 *>(Vh + kl_ * VS + vswz(kl_, ch * 8)) = vh;
                 *reinterpret_cast<f16x8 *>(Vl + kl_ * VS + vswz(kl_, ch * 8)) = vl;
             }
@@ -404,11 +407,13 @@ __global__ void __launch_bounds__(64 * NW, 2) attention_split_kernel(const float
                 f32x4 x0 = xq[2 * sx], x1 = xq[2 * sx + 1];
                 x0 = x0 * qscale;
                 x1 = x1 * qscale;
-                f16x4 a0, a1, c0, c1;
-                pair_split4_scaled(x0, SC, &a0, &c0);
-                pair_split4_scaled(x1, SC, &a1, &c1);
-                qh[sx] = f16x8{a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
-                ql[sx] = f16x8{c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
+                const f16x4 a0 = cvt_f16x4_pinned(x0), a1 = cvt_f16x4_pinned(x1);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    qh[sx][j] = a0[j]; qh[sx][4 + j] = a1[j];
+                    ql[sx][j] = (_Float16)((x0[j] - (float)a0[j]) * SC);
+                    ql[sx][4 + j] = (_Float16)((x1[j] - (float)a1[j]) * SC);
+                }
             }
         }
         float m_run = -INFINITY, l_run = 0.0f;
@@ -463,11 +468,15 @@ __global__ void __launch_bounds__(64 * NW, 2) attention_split_kernel(const float
                 om0 *= alpha; om1 *= alpha; oc0 *= alpha; oc1 *= alpha;
 #pragma unroll
                 for (int uu = 0; uu < 2; ++uu) {
-                    f16x4 h0, h1, r0, r1;
-                    pair_split4_scaled(f32x4{p[8 * uu], p[8 * uu + 1], p[8 * uu + 2], p[8 * uu + 3]}, SC, &h0, &r0);
-                    pair_split4_scaled(f32x4{p[8 * uu + 4], p[8 * uu + 5], p[8 * uu + 6], p[8 * uu + 7]}, SC, &h1, &r1);
-                    const f16x8 ph = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
-                    const f16x8 pl = {r0[0], r0[1], r0[2], r0[3], r1[0], r1[1], r1[2], r1[3]};
+                    const f16x4 h0 = cvt_f16x4_pinned(f32x4{p[8 * uu], p[8 * uu + 1], p[8 * uu + 2], p[8 * uu + 3]});
+                    const f16x4 h1 = cvt_f16x4_pinned(f32x4{p[8 * uu + 4], p[8 * uu + 5], p[8 * uu + 6], p[8 * uu + 7]});
+                    f16x8 ph, pl;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        ph[j] = h0[j]; ph[4 + j] = h1[j];
+                        pl[j] = (_Float16)((p[8 * uu + j] - (float)h0[j]) * SC);
+                        pl[4 + j] = (_Float16)((p[8 * uu + 4 + j] - (float)h1[j]) * SC);
+                    }
                     const int kcol = kb * 32 + 16 * uu + 4 * g;
                     // V^T fragment of head dims row .. (lane i), keys kcol + {0..3, 8..11}
                     auto vfrag = [&](const _Float16 *V, int row) {

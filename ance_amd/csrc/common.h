@@ -77,40 +77,14 @@ __device__ __forceinline__ f16x4 cvt_f16x4_pinned(const f32x4 v) {
 constexpr float PAIR_LO_SCALE = 1.0f, PAIR_LO_INV = 1.0f;
 __host__ __device__ __forceinline__ int pair_hi_col(int n, int W) { (void)W; return ((n >> 5) << 6) + (n & 31); }
 __host__ __device__ __forceinline__ int pair_lo_col(int n, int W) { (void)W; return ((n >> 5) << 6) + (n & 31) + 32; }
-// f32 <- (f16 half of a packed register) * m + c in ONE instruction (v_fma_mix_f32: the conversion is part of the fma, and the half is
-// taken where it sits -- low or high 16 bits -- so a pair needs neither v_cvt_f32_f16 nor an unpacking move).  HALF: 0 low, 1 high.
-template <int HALF>
-__device__ __forceinline__ float fma_mix_f16(unsigned packed, float m, float c) {
-    float d;
-    if constexpr (HALF == 0) asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(d) : "v"(packed), "v"(m), "v"(c));
-    else asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(packed), "v"(m), "v"(c));
-    return d;
-}
-// f32 <- hi + lo of a pair whose halves sit in the same half (HALF) of two packed registers: one v_fma_mix_f32 (hi * 1 + lo) instead of
-// two conversions and an add.  Exact: a pair's sum has at most 22 significant bits.
-template <int HALF>
-__device__ __forceinline__ float pair_join_mix(unsigned hi_packed, unsigned lo_packed) {
-    float d;
-    if constexpr (HALF == 0) asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel_hi:[1,0,1]" : "=v"(d) : "v"(hi_packed), "v"(lo_packed));
-    else asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(d) : "v"(hi_packed), "v"(lo_packed));
-    return d;
-}
-typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-// v (4 consecutive columns) -> the two f16x4 of its pair; the hi that is stored is the hi the residual was formed from.
-// v - hi is exact in fp32; round 6 forms it as fma_mix(hi, -1, v): one instruction per element instead of a conversion and a
-// subtraction (the pair epilogues are bound by their vector ALU work), the same bits (tools/tr16_probe.cpp checks it on the device,
-// subnormal hi halves included).
-__device__ __forceinline__ void pair_split4_scaled(const f32x4 v, const float lo_scale, f16x4 *hi, f16x4 *lo) {
+// v (4 consecutive columns) -> the two f16x4 of its pair; the hi that is stored is the hi the residual was formed from
+__device__ __forceinline__ void pair_split4(const f32x4 v, f16x4 *hi, f16x4 *lo) {
 #pragma clang fp contract(off)
     const f16x4 h = cvt_f16x4_pinned(v);
     *hi = h;
-    const u32x2 hp = __builtin_bit_cast(u32x2, h);
-    const float d0 = fma_mix_f16<0>(hp[0], -1.0f, v[0]), d1 = fma_mix_f16<1>(hp[0], -1.0f, v[1]);
-    const float d2 = fma_mix_f16<0>(hp[1], -1.0f, v[2]), d3 = fma_mix_f16<1>(hp[1], -1.0f, v[3]);
-    *lo = f16x4{(_Float16)(d0 * lo_scale), (_Float16)(d1 * lo_scale), (_Float16)(d2 * lo_scale), (_Float16)(d3 * lo_scale)};
+    *lo = f16x4{(_Float16)((v[0] - (float)h[0]) * PAIR_LO_SCALE), (_Float16)((v[1] - (float)h[1]) * PAIR_LO_SCALE),
+                (_Float16)((v[2] - (float)h[2]) * PAIR_LO_SCALE), (_Float16)((v[3] - (float)h[3]) * PAIR_LO_SCALE)};
 }
-__device__ __forceinline__ void pair_split4(const f32x4 v, f16x4 *hi, f16x4 *lo) { pair_split4_scaled(v, PAIR_LO_SCALE, hi, lo); }
 // store / load columns n .. n + 3 (n a multiple of 4) of a pair row of width W
 __device__ __forceinline__ void pair_store4(const f32x4 v, _Float16 *row, int W, int n) {
     f16x4 h, r;

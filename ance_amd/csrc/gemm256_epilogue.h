@@ -568,20 +568,11 @@ __device__ __forceinline__ void gemm256_epilogue_split(const GemmArgs &G, f32x16
             for (int h = 0; h < NV; ++h) {
                 f32x4 a = *reinterpret_cast<const f32x4 *>(slab + rr * LS + cl * CPL + 4 * h);
                 if constexpr (EPI == EPI_S_RESLN) {
-                    // residual = hi + lo, exact in fp32 (22 bits): one v_fma_mix_f32 per element, the halves taken where they sit in
-                    // their packed registers (round 6: the epilogue is bound by its vector ALU work)
-                    static_assert(PAIR_LO_INV == 1.0f, "pair_join_mix adds the lo half unscaled");
-                    const u32x4 hp = __builtin_bit_cast(u32x4, rh[it]), lp = __builtin_bit_cast(u32x4, rl[it]);
-                    // (two columns at a time on the packed fp32 pipe, spelled out: the compiler does not pair up what comes out of an asm)
 #pragma unroll
-                    for (int p = 0; p < 2; ++p) {
-                        const f32x2 ra = {pair_join_mix<0>(hp[2 * h + p], lp[2 * h + p]), pair_join_mix<1>(hp[2 * h + p], lp[2 * h + p])};
-                        const f32x2 ga = f32x2{rstd[it], rstd[it]} * f32x2{v1[h][2 * p], v1[h][2 * p + 1]};
-                        const f32x2 c = f32x2{v0[h][2 * p], v0[h][2 * p + 1]} + f32x2{v2[h][2 * p], v2[h][2 * p + 1]};
-                        const f32x2 t = __builtin_elementwise_fma(ra - f32x2{mean[it], mean[it]}, ga, c);
-                        const f32x2 o = __builtin_elementwise_fma(f32x2{a[2 * p], a[2 * p + 1]}, f32x2{winv, winv}, t);
-                        a[2 * p] = o[0];
-                        a[2 * p + 1] = o[1];
+                    for (int e = 0; e < 4; ++e) {
+                        const float ga = rstd[it] * v1[h][e];
+                        const float ra = (float)rh[it][4 * h + e] + (float)rl[it][4 * h + e] * PAIR_LO_INV;  // exact in fp32: 22 bits
+                        a[e] = __builtin_fmaf(a[e], winv, __builtin_fmaf(ra - mean[it], ga, v0[h][e] + v2[h][e]));
                     }
                 } else {
                     const float mr = mean[it] * rstd[it], rw = rstd[it] * winv;  // r (acc winv) = acc (r winv): winv is a power of two
@@ -675,15 +666,10 @@ __device__ __forceinline__ void gemm256_epilogue_split32(const GemmArgs &G, f32x
                 f32x4 a = *reinterpret_cast<const f32x4 *>(slab + rr * LS + cl * CPL + 4 * h);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) a[e] = __builtin_fmaf(a[e], rw, __builtin_fmaf(-mr, v1[h][e], v0[h][e]));
-#if !defined(GS_DIAG_NO_GELU)
                 if constexpr (EPI == EPI_S_GELU) a = gelu_exact4(a);
-#endif
                 range_track4(a, &vmax);
                 vv[h] = a;
             }
-#if defined(GS_DIAG_NO_STORE)  // measurement build (scripts/gpu_r6_epi_phases.sh): the epilogue without its output stores
-            if (G.M < 0)
-#endif
             if constexpr (EPI == EPI_S_QKV) EPI_F32_STORE(reinterpret_cast<f32x4 *>(G.out32 + row * G.ldc + n), vv[0]);
             else EPI_PAIR_STORE8(vv[0], vv[NV - 1], G.out16 + row * G.ldc, G.N, n);
         }

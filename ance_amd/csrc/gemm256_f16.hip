@@ -396,9 +396,6 @@ __global__ void __launch_bounds__(G256_THREADS, 2) gemm256_split_stream_kernel(c
     };
     int mt, nt;
     if (!next_tile(&mt, &nt)) return;
-#if defined(GS_DIAG_STAGGER)  // measurement build: the workgroups of XCD k start k * GS_DIAG_STAGGER sleeps (~4 us each) late
-    for (int z = 0; z < xcd * GS_DIAG_STAGGER; ++z) __builtin_amdgcn_s_sleep(127);
-#endif
     Pipe256T<PipeSrcStream, false, true, true, true> P;
     P.init(smem, w, l);
     P.S.ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16 *>(G.A), 0, (int)((uint32_t)G.M * (uint32_t)G.lda * 2u), 0x00020000);
@@ -558,17 +555,6 @@ int gemm_stream_mode() {
     }
     return g_gemm_stream;
 }
-// ANCE_GEMM_STREAM_WGS: workgroups of the persistent kernels (default: one per CU).  With the encoder's two internal streams a
-// smaller grid leaves CUs to the other micro-batch's kernels (measured: scripts/gpu_r6_stream_wgs.sh).
-int g_gemm_stream_wgs = -1;
-int gemm_stream_wgs() {
-    if (g_gemm_stream_wgs < 0) {
-        const char *e = getenv("ANCE_GEMM_STREAM_WGS");
-        g_gemm_stream_wgs = e ? (atoi(e) & ~7) : 0;
-        if (g_gemm_stream_wgs < 0) g_gemm_stream_wgs = 0;
-    }
-    return g_gemm_stream_wgs;
-}
 int device_cu_count() {
     static int cus[64] = {0};
     int dev = 0;
@@ -635,8 +621,7 @@ int launch256(int epi, const GemmArgs &G, hipStream_t st) {
                 return check_launch("gemm256 stream attr");
             attr_mark(&sattr_done[epi - EPI_S_QKV]);
         }
-        unsigned cus = (unsigned)device_cu_count() & ~7u;  // one workgroup per CU (160 KiB of LDS each), a multiple of the 8 XCDs
-        if (gemm_stream_wgs() >= 8 && (unsigned)gemm_stream_wgs() < cus) cus = (unsigned)gemm_stream_wgs();
+        const unsigned cus = (unsigned)device_cu_count() & ~7u;  // one workgroup per CU (160 KiB of LDS each), a multiple of the 8 XCDs
         const unsigned grid = blocks < cus ? blocks : cus;
         hipLaunchKernelGGL(ks, dim3(grid), dim3(G256_THREADS), GS_LDS_BYTES, st, G, (int)blocks);
         return ANCE_OK;
@@ -656,7 +641,7 @@ int launch256(int epi, const GemmArgs &G, hipStream_t st) {
 
 }  // namespace
 
-void reload_gemm_knobs() { g_gemm_stream = -1; g_gemm_stream_wgs = -1; }
+void reload_gemm_knobs() { g_gemm_stream = -1; }
 
 bool gemm256_applicable(const GemmArgs &G) {
     return G.M > 0 && G.N > 0 && G.K >= 2 * TK && G.M % TM == 0 && G.N % TN == 0 && G.K % TK == 0;

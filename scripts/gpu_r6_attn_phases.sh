@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round 6: what the split attention kernel's phases cost -- the product against measurement builds without the K / V staging
 # (ATTN_DIAG_NO_STAGE: no panel loads, no split, zeros written to the LDS), without the panel's global loads only (ATTN_DIAG_NO_LOAD),
-# without the key-block loop (ATTN_DIAG_NO_COMPUTE); and the padded V rows of the first transpose-read form (ANCE_ATTN_V_PAD).  Also the
+# without the key-block loop (ATTN_DIAG_NO_COMPUTE).  (The padded V rows of the first transpose-read form, ANCE_ATTN_V_PAD, were a fourth variant at commit fff5260.)  Also the
 # v_fma_mix_f32 probe of pair_split4 and the GEMM / encoder bit tests of the tree.
 set -u
 cd "$(dirname "$0")/.."
@@ -19,6 +19,6 @@ print(json.dumps({'variant': '$1', 'passages_per_sec': d['value'], 'ms_per_step'
 }
 for rep in 1 2; do
   one product ance_amd/libance_amd.so
-  for v in ${VARIANTS:-vpad nostage noload nocompute}; do one $v ance_amd/libance_amd_$v.so; done
+  for v in ${VARIANTS:-nostage noload nocompute}; do one $v ance_amd/libance_amd_$v.so; done
 done
 cat gpurun_out/ab_attn_phases.jsonl
