@@ -534,36 +534,18 @@ __device__ __forceinline__ void gemm256_epilogue_split(const GemmArgs &G, f32x16
     }
     const int n_parts = G.N >> 6, slice = nw0 >> 6;
     float vmax = 0.f;  // range guard: running maximum of |what this thread stores| (common.h)
-    // EPI_S_RESLN: the residual pair rows of pass y + 1 are requested at the top of pass y (two register sets).  vmcnt retires in
-    // order: a pass that requests its own rows waits for them BEHIND the previous pass's stores -- one store drain + one load latency
-    // per pass, four times per tile; a pass ahead, the rows travel under a whole pass of arithmetic and the wait counts the stores
-    // issued after them instead of waiting for them (ANCE_RESLN_NO_PREFETCH: the first form, for the A/B).
-#if defined(ANCE_RESLN_NO_PREFETCH)
-    constexpr bool RES_AHEAD = false;
-#else
-    constexpr bool RES_AHEAD = EPI == EPI_S_RESLN;
-#endif
-    f16x8 rhA[ITS], rlA[ITS], rhB[ITS], rlB[ITS];  // register sets of the even / odd passes (the y loop is unrolled: every choice below folds)
-#define EPI_REQUEST_RESIDUAL(Y, RH, RL)                                                                       \
-    _Pragma("unroll") for (int it_ = 0; it_ < ITS; ++it_) {                                                   \
-        const _Float16 *rp_ = G.res_hi + (size_t)(mw0 + (Y) * 32 + it_ * RPI + rl_) * G.ldr;                 \
-        RH[it_] = *reinterpret_cast<const f16x8 *>(rp_ + pair_hi_col(nc, G.N));                              \
-        RL[it_] = *reinterpret_cast<const f16x8 *>(rp_ + pair_lo_col(nc, G.N));                              \
-    }
-    if constexpr (RES_AHEAD) { EPI_REQUEST_RESIDUAL(0, rhA, rlA) }
 #pragma unroll
     for (int y = 0; y < 4; ++y) {
+        f16x8 rh[ITS], rl[ITS];
         float mean[ITS], rstd[ITS];
-        if constexpr (EPI == EPI_S_RESLN) {
-            if constexpr (!RES_AHEAD) {
-                EPI_REQUEST_RESIDUAL(y, rhA, rlA)
-            } else if (y + 1 < 4) {
-                if ((y + 1) & 1) { EPI_REQUEST_RESIDUAL(y + 1, rhB, rlB) } else { EPI_REQUEST_RESIDUAL(y + 1, rhA, rlA) }
-            }
-        }
 #pragma unroll
         for (int it = 0; it < ITS; ++it) {
             const int rr = it * RPI + rl_;
+            if constexpr (EPI == EPI_S_RESLN) {
+                const _Float16 *rp = G.res_hi + (size_t)(mw0 + y * 32 + rr) * G.ldr;
+                rh[it] = *reinterpret_cast<const f16x8 *>(rp + pair_hi_col(nc, G.N));
+                rl[it] = *reinterpret_cast<const f16x8 *>(rp + pair_lo_col(nc, G.N));
+            }
             mean[it] = pb[EPB_STATS + 2 * (wm * 128 + y * 32 + rr)];
             rstd[it] = pb[EPB_STATS + 2 * (wm * 128 + y * 32 + rr) + 1];
         }
@@ -582,7 +564,6 @@ __device__ __forceinline__ void gemm256_epilogue_split(const GemmArgs &G, f32x16
         for (int it = 0; it < ITS; ++it) {
             const int rr = it * RPI + rl_;
             const size_t row = (size_t)(mw0 + y * 32 + rr);
-            const f16x8 rhv = (RES_AHEAD && (y & 1)) ? rhB[it] : rhA[it], rlv = (RES_AHEAD && (y & 1)) ? rlB[it] : rlA[it];
 #pragma unroll
             for (int h = 0; h < NV; ++h) {
                 f32x4 a = *reinterpret_cast<const f32x4 *>(slab + rr * LS + cl * CPL + 4 * h);
@@ -590,7 +571,7 @@ __device__ __forceinline__ void gemm256_epilogue_split(const GemmArgs &G, f32x16
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const float ga = rstd[it] * v1[h][e];
-                        const float ra = (float)rhv[4 * h + e] + (float)rlv[4 * h + e] * PAIR_LO_INV;  // exact in fp32: 22 bits
+                        const float ra = (float)rh[it][4 * h + e] + (float)rl[it][4 * h + e] * PAIR_LO_INV;  // exact in fp32: 22 bits
                         a[e] = __builtin_fmaf(a[e], winv, __builtin_fmaf(ra - mean[it], ga, v0[h][e] + v2[h][e]));
                     }
                 } else {
@@ -628,7 +609,6 @@ __device__ __forceinline__ void gemm256_epilogue_split(const GemmArgs &G, f32x16
         }
     }
     range_report(vmax, G.range_faults);
-#undef EPI_REQUEST_RESIDUAL
 }
 
 // ---- epilogues of the STREAMING (persistent) split GEMM: EPI_S_QKV and EPI_S_GELU -----------------------------------------
