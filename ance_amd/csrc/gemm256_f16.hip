@@ -377,7 +377,7 @@ __device__ __forceinline__ void eps_barrier() {
 }
 
 template <int EPI>
-__global__ void __launch_bounds__(G256_THREADS, 2) gemm256_split_stream_kernel(const GemmArgs G, const int n_blocks, const int stagger) {
+__global__ void __launch_bounds__(G256_THREADS, 2) gemm256_split_stream_kernel(const GemmArgs G, const int n_blocks) {
     extern __shared__ __attribute__((aligned(16))) float smem_f[];
     _Float16 *smem = reinterpret_cast<_Float16 *>(smem_f);
     const int tid = threadIdx.x;
@@ -396,8 +396,6 @@ __global__ void __launch_bounds__(G256_THREADS, 2) gemm256_split_stream_kernel(c
     };
     int mt, nt;
     if (!next_tile(&mt, &nt)) return;
-    // (measurement: ANCE_GEMM_STAGGER -- the workgroups of XCD k start k * stagger sleeps of ~4.8 us late)
-    for (int z = 0; z < xcd * stagger; ++z) __builtin_amdgcn_s_sleep(127);
     Pipe256T<PipeSrcStream, false, true, true, true> P;
     P.init(smem, w, l);
     P.S.ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16 *>(G.A), 0, (int)((uint32_t)G.M * (uint32_t)G.lda * 2u), 0x00020000);
@@ -557,21 +555,6 @@ int gemm_stream_mode() {
     }
     return g_gemm_stream;
 }
-// ANCE_GEMM_STAGGER=s, ANCE_GEMM_STAGGER_EVERY=n (measurement): every n-th launch of a persistent kernel starts the workgroups of
-// XCD k  k * s sleeps late -- does a stagger set up once survive through the kernels that follow on the encoder's two streams?
-int g_gemm_stagger = -1, g_gemm_stagger_every = 1;
-unsigned g_gemm_stream_launches = 0;
-int gemm_stagger_of_this_launch() {
-    if (g_gemm_stagger < 0) {
-        const char *e = getenv("ANCE_GEMM_STAGGER"), *n = getenv("ANCE_GEMM_STAGGER_EVERY");
-        g_gemm_stagger = e ? atoi(e) : 0;
-        if (g_gemm_stagger < 0 || g_gemm_stagger > 16) g_gemm_stagger = 0;
-        g_gemm_stagger_every = n ? atoi(n) : 1;
-        if (g_gemm_stagger_every < 1) g_gemm_stagger_every = 1;
-    }
-    const unsigned i = __atomic_fetch_add(&g_gemm_stream_launches, 1u, __ATOMIC_RELAXED);
-    return (g_gemm_stagger > 0 && i % (unsigned)g_gemm_stagger_every == 0) ? g_gemm_stagger : 0;
-}
 int device_cu_count() {
     static int cus[64] = {0};
     int dev = 0;
@@ -631,7 +614,7 @@ int launch256(int epi, const GemmArgs &G, hipStream_t st) {
         && !(epi == g_gemm_stamps_epi && g_gemm_stamps_host)
 #endif
     ) {
-        void (*ks)(const GemmArgs, int, int) = epi == EPI_S_QKV ? gemm256_split_stream_kernel<EPI_S_QKV> : gemm256_split_stream_kernel<EPI_S_GELU>;
+        void (*ks)(const GemmArgs, int) = epi == EPI_S_QKV ? gemm256_split_stream_kernel<EPI_S_QKV> : gemm256_split_stream_kernel<EPI_S_GELU>;
         static unsigned long long sattr_done[2] = {0, 0};
         if (attr_needed(&sattr_done[epi - EPI_S_QKV])) {
             if (hipFuncSetAttribute(reinterpret_cast<const void *>(ks), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GS_LDS_BYTES) != hipSuccess)
@@ -640,7 +623,7 @@ int launch256(int epi, const GemmArgs &G, hipStream_t st) {
         }
         const unsigned cus = (unsigned)device_cu_count() & ~7u;  // one workgroup per CU (160 KiB of LDS each), a multiple of the 8 XCDs
         const unsigned grid = blocks < cus ? blocks : cus;
-        hipLaunchKernelGGL(ks, dim3(grid), dim3(G256_THREADS), GS_LDS_BYTES, st, G, (int)blocks, gemm_stagger_of_this_launch());
+        hipLaunchKernelGGL(ks, dim3(grid), dim3(G256_THREADS), GS_LDS_BYTES, st, G, (int)blocks);
         return ANCE_OK;
     }
     const size_t lds = epi >= EPI_RESLN ? G256_LDS_BYTES + (size_t)EPB_FLOATS * sizeof(float) : G256_LDS_BYTES;
@@ -658,7 +641,7 @@ int launch256(int epi, const GemmArgs &G, hipStream_t st) {
 
 }  // namespace
 
-void reload_gemm_knobs() { g_gemm_stream = -1; g_gemm_stagger = -1; }
+void reload_gemm_knobs() { g_gemm_stream = -1; }
 
 bool gemm256_applicable(const GemmArgs &G) {
     return G.M > 0 && G.N > 0 && G.K >= 2 * TK && G.M % TM == 0 && G.N % TN == 0 && G.K % TK == 0;
