@@ -179,15 +179,17 @@ __global__ void __launch_bounds__(64 * NW, 3) attention_kernel(const AttnArgs A)
     // accesses per instruction instead of 8.
     const int q_end = A.cls_only ? 1 : T;  // last layer: only the [CLS] query feeds the head
     f16x8 qf[4];
+    // (q_compact: the one query of sequence s is row s of the Q columns -- encoder.hip projects the [CLS] rows compactly)
+    auto q_row = [&](int r) { return A.q_compact ? (size_t)s : (size_t)(tok0 + min(r, T - 1)); };
     auto q_request = [&](int qb0) {
         if constexpr (COAL) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int row = j * 8 + (l >> 3);
-                qf[j] = *reinterpret_cast<const f16x8 *>(A.qk + (size_t)(tok0 + min(qb0 + row, T - 1)) * A.ld_qk + h * HD + (l & 7) * 8);
+                qf[j] = *reinterpret_cast<const f16x8 *>(A.qk + q_row(qb0 + row) * A.ld_qk + h * HD + (l & 7) * 8);
             }
         } else {
-            const _Float16 *qp = A.qk + (size_t)(tok0 + min(qb0 + i, T - 1)) * A.ld_qk + h * HD + 32 * g;
+            const _Float16 *qp = A.qk + q_row(qb0 + i) * A.ld_qk + h * HD + 32 * g;
 #pragma unroll
             for (int sx = 0; sx < 4; ++sx) qf[sx] = *reinterpret_cast<const f16x8 *>(qp + sx * 8);
         }
@@ -394,7 +396,8 @@ __global__ void __launch_bounds__(64 * NW, 2) attention_split_kernel(const float
         // Q fragments (B operand: lane (query i, group g) holds head dims 32 g + 8 sx .. + 8), scaled, then split
         f16x8 qh[4], ql[4];
         {
-            const float *qp = qkv + (size_t)(tok0 + min(qb0 + i, T - 1)) * ld + h * HD + 32 * g;
+            // (cls_only: the one query of sequence s is row s of the Q columns -- encoder.hip projects the [CLS] rows compactly)
+            const float *qp = qkv + (cls_only ? (size_t)s : (size_t)(tok0 + min(qb0 + i, T - 1))) * ld + h * HD + 32 * g;
             f32x4 xq[8];
 #pragma unroll
             for (int sx = 0; sx < 8; ++sx) xq[sx] = *reinterpret_cast<const f32x4 *>(qp + sx * 4);

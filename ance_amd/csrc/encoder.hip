@@ -1076,15 +1076,37 @@ int encode_impl(AnceEncoder *e, const int32_t *base, int64_t ld, const int32_t *
                     G.A = xb; G.lda = HP; G.B = W.wqkv_s; G.ldb = HP; G.M = Tpad; G.N = 3 * H; G.K = H;
                     G.bias = W.bqkv_s; G.csum = W.cqkv_s; G.part_in = LN.partB; G.ln_eps = eps_b;
                     G.out32 = LN.qkv32; G.ldc = 3 * H; G.wscale_inv = W.sc_s + 4; G.range_faults = e->faults;
+                    // CLS-only tail: the last layer's attention has ONE query per sequence.  K | V of every token, but Q of the [CLS]
+                    // rows only: their pair rows and slice partials are compacted first (they are also the residual of the
+                    // attention-output GEMM below) and projected by a second, small launch into the Q columns of rows 0 .. S_pad of
+                    // qkv32 -- row s = the query of sequence s (attention_split_kernel, cls_only).  A third of this GEMM's work in one
+                    // layer of twelve; every element is the same arithmetic as in the full launch.
+                    const bool tail_q = tail && e->split_attn;
+                    float *const cpt = reinterpret_cast<float *>(ffnp + (size_t)S_pad * HP);  // (the FFN buffer is dead here)
+                    if (tail) {
+                        ProfScope ps(PC_LN, st);
+                        hipLaunchKernelGGL(gather_cls_split_kernel, dim3(S_pad / 4), dim3(256), 0, st, xb, LN.partB, LN.seq_off, S, S_pad,
+                                           ffnp, cpt);
+                    }
                     {
-                        ProfScope ps(PC_GEMM_QK, st, 2.0 * T * (3.0 * H) * H);
-                        rc = launch_gemm_f16(EPI_S_QKV, G, st);
+                        ProfScope ps(PC_GEMM_QK, st, tail_q ? 2.0 * T * (2.0 * H) * H + 2.0 * S * (double)H * H : 2.0 * T * (3.0 * H) * H);
+                        if (tail_q) {
+                            G.B = W.wqkv_s + (size_t)H * HP; G.N = 2 * H; G.bias = W.bqkv_s + H; G.csum = W.cqkv_s + H;
+                            G.out32 = LN.qkv32 + H;
+                            rc = launch_gemm_f16(EPI_S_QKV, G, st);
+                            G.A = ffnp; G.part_in = cpt; G.M = S_pad;
+                            G.B = W.wqkv_s; G.N = H; G.bias = W.bqkv_s; G.csum = W.cqkv_s; G.out32 = LN.qkv32;
+                            if (!rc) rc = launch_gemm_f16(EPI_S_QKV, G, st);
+                        } else {
+                            rc = launch_gemm_f16(EPI_S_QKV, G, st);
+                        }
                     }
                     if (rc) break;
                     {
                         ProfScope ps(PC_ATTN, st);
                         if (tail && S_pad > S)  // rows S..S_pad of the compact attention output feed the GEMM tile: keep them finite
                             (void)hipMemsetAsync(ctxp + (size_t)S * HP, 0, (size_t)(S_pad - S) * HP * sizeof(_Float16), st);
+                        // (cls_only: one query per sequence, read from row s of the Q columns -- the tail's compact Q projection above)
                         rc = e->split_attn ? launch_attention_split(LN.qkv32, ctxp, LN.desc, S, D.n_heads, maxlen, tail ? 1 : 0, st)
                                            : ANCE_E_INVALID;
                         if (rc == ANCE_E_INVALID)  // ANCE_SPLIT_ATTN=0: the fp32 vector-unit kernel (A/B)
@@ -1096,11 +1118,7 @@ int encode_impl(AnceEncoder *e, const int32_t *base, int64_t ld, const int32_t *
                     G.res_gamma = li == 0 ? e->eln_w : e->layers[li - 1].ln2w;
                     G.res_beta = li == 0 ? e->eln_b : e->layers[li - 1].ln2b;
                     G.res_hi = xb; G.ldr = HP; G.part_in = LN.partB; G.ln_eps = eps_b; G.range_faults = e->faults;
-                    if (tail) {  // compact pair rows + partials of the [CLS] tokens, parked in the (currently dead) FFN buffer
-                        float *cpt = reinterpret_cast<float *>(ffnp + (size_t)S_pad * HP);
-                        ProfScope ps(PC_LN, st);
-                        hipLaunchKernelGGL(gather_cls_split_kernel, dim3(S_pad / 4), dim3(256), 0, st, xb, LN.partB, LN.seq_off, S, S_pad,
-                                           ffnp, cpt);
+                    if (tail) {  // the compact pair rows + partials of the [CLS] tokens (gathered in front of the QKV GEMM)
                         G.res_hi = ffnp; G.part_in = cpt;
                     }
                     G.A = ctxp; G.lda = HP; G.B = W.wo_s; G.ldb = HP; G.M = Mrows; G.N = H; G.K = H;
@@ -1182,10 +1200,28 @@ int encode_impl(AnceEncoder *e, const int32_t *base, int64_t ld, const int32_t *
                 G.bias = W.bqk; G.out16 = LN.qk16; G.ldc = 2 * H; G.scale_cols = H;
                 G.scale = 0.125f * 1.44269504088896340736f;  // 1/sqrt(64) and log2(e): the softmax runs on exp2
                 G.part_in = LN.partB; G.ln_eps = D.ln_eps; G.csum = W.cqk; G.tok_lo = fold ? xb_lo : nullptr;
+                // CLS-only tail (folded form): K of every token, Q of the compact [CLS] rows only -- row s of the Q columns is the query
+                // of sequence s (attention_kernel, cls_only); the same arithmetic per element as the full launch (split mode: above)
+                const bool tail_q = tail && fold;
+                _Float16 *const chi = LN.ffn16, *const clo = chi + (size_t)S_pad * H;  // (the FFN buffer is dead here)
+                float *const cpt = reinterpret_cast<float *>(clo + (size_t)S_pad * H);
+                if (tail_q) {
+                    ProfScope ps(PC_LN, st);
+                    hipLaunchKernelGGL(gather_cls_fold_kernel, dim3(S_pad / 4), dim3(256), 0, st, xb_hi, xb_lo, LN.partB, LN.seq_off,
+                                       S, S_pad, chi, clo, cpt);
+                }
                 int rc;
                 {
-                    ProfScope ps(PC_GEMM_QK, st, 2.0 * T * (2.0 * H) * H);
-                    rc = launch_gemm_f16(fold ? EPI_QK_F : EPI_QK, G, st);
+                    ProfScope ps(PC_GEMM_QK, st, tail_q ? 2.0 * T * (double)H * H + 2.0 * S * (double)H * H : 2.0 * T * (2.0 * H) * H);
+                    if (tail_q) {
+                        G.B = W.wqk + (size_t)H * H; G.N = H; G.bias = W.bqk + H; G.csum = W.cqk + H; G.out16 = LN.qk16 + H; G.scale_cols = 0;
+                        rc = launch_gemm_f16(EPI_QK_F, G, st);
+                        G.A = chi; G.tok_lo = clo; G.part_in = cpt; G.M = S_pad;
+                        G.B = W.wqk; G.bias = W.bqk; G.csum = W.cqk; G.out16 = LN.qk16; G.scale_cols = H;
+                        if (!rc) rc = launch_gemm_f16(EPI_QK_F, G, st);
+                    } else {
+                        rc = launch_gemm_f16(fold ? EPI_QK_F : EPI_QK, G, st);
+                    }
                 }
                 if (rc) return rc;
                 // V^T = Wv h^T
@@ -1200,7 +1236,7 @@ int encode_impl(AnceEncoder *e, const int32_t *base, int64_t ld, const int32_t *
                 if (rc) return rc;
                 AttnArgs A;
                 A.qk = LN.qk16; A.vt = LN.vt16; A.ctx = LN.ctx16; A.desc = LN.desc;
-                A.ld_qk = 2 * H; A.ld_vt = ldvt; A.ld_ctx = H; A.n_heads = D.n_heads; A.cls_only = tail ? 1 : 0; A.coalesced = e->attn_coal ? 1 : 0;
+                A.ld_qk = 2 * H; A.ld_vt = ldvt; A.ld_ctx = H; A.n_heads = D.n_heads; A.cls_only = tail ? 1 : 0; A.q_compact = tail_q ? 1 : 0; A.coalesced = e->attn_coal ? 1 : 0;
                 {
                     ProfScope ps(PC_ATTN, st, 0.0);
                     rc = launch_attention(A, S, maxlen, st);
@@ -1214,12 +1250,7 @@ int encode_impl(AnceEncoder *e, const int32_t *base, int64_t ld, const int32_t *
                 G.res_stats = LN.statsB; G.res_gamma = rg; G.res_beta = rb;
                 if (fold) {
                     G.res_hi = xb_hi; G.res_lo = xb_lo; G.part_in = LN.partB; G.ln_eps = D.ln_eps;
-                    if (tail) {  // compact (hi, lo, partials) rows of the [CLS] tokens, parked in the (currently dead) FFN buffer
-                        _Float16 *chi = LN.ffn16, *clo = chi + (size_t)S_pad * H;
-                        float *cpt = reinterpret_cast<float *>(clo + (size_t)S_pad * H);
-                        ProfScope ps(PC_LN, st);
-                        hipLaunchKernelGGL(gather_cls_fold_kernel, dim3(S_pad / 4), dim3(256), 0, st, xb_hi, xb_lo, LN.partB, LN.seq_off,
-                                           S, S_pad, chi, clo, cpt);
+                    if (tail) {  // the compact (hi, lo, partials) rows of the [CLS] tokens (gathered in front of the Q | K GEMM)
                         G.res_hi = chi; G.res_lo = clo; G.part_in = cpt;
                     }
                     G.out16 = xa_hi; G.out_lo = xa_lo; G.part_out = LN.partA;

@@ -176,6 +176,31 @@ def test_many_short_queries_cross_micro_batches():
     _report("short_queries", got[pick], want)
 
 
+@pytest.mark.parametrize("precision", ["split", "fp16"])
+def test_cls_only_tail_changes_no_bit(monkeypatch, precision):
+    """The last layer runs K | V for every token and everything else -- the Q projection (a compact GEMM over the [CLS] rows),
+    the attention (one query per sequence), attention-output, FFN -- for the [CLS] rows only.  Dead work of the reference's forward
+    (model/models.py:149-157 reads token 0 only), not different arithmetic: against the full last layer (ANCE_CLS_TAIL=0) not one
+    bit of an embedding may differ, in either matrix-core mode, with one and with several micro-batches."""
+    from ance_amd.encoder import ARCH_ROBERTA, Encoder
+    from oracle import encoder_ref, synth
+    sd = encoder_ref.random_state_dict(seed=25, n_layers=3, ln_jitter=0.1)
+    rng = np.random.default_rng(28)
+    lens = np.concatenate([np.array([1, 2, 31, 32, 33, 64, 65, 96, 97, 128], dtype=np.int32), rng.integers(3, 129, 390).astype(np.int32)])
+    ids = synth.make_records(rng, len(lens), 128, lens.astype(np.int64))
+
+    def run(max_tokens):
+        enc = Encoder(sd, ARCH_ROBERTA, "roberta.", True, max_seq_len=128, max_tokens=max_tokens, precision=precision)
+        return enc.encode_ids(torch.from_numpy(ids).cuda(), torch.from_numpy(lens).cuda(), h_lens=lens)
+
+    tail, tail_small = run(65536), run(4096)
+    monkeypatch.setenv("ANCE_CLS_TAIL", "0")
+    full = run(65536)
+    assert torch.isfinite(tail).all()
+    assert torch.equal(tail, full)
+    assert torch.equal(tail_small, full)
+
+
 @pytest.mark.parametrize("switch", ["ANCE_LN_FOLD", "ANCE_HEAD_MFMA", "ANCE_ATTN_COAL", "ANCE_CLS_TAIL", "ANCE_ENCODER_STREAMS"])
 def test_ab_switches_keep_parity(monkeypatch, switch):
     """The A/B switches of include/ance_amd.h select the previous form of one piece each (LayerNorm kernels instead of the
@@ -332,9 +357,13 @@ def test_split_mode_against_oracle(monkeypatch):
     assert d <= 2e-5, d
     assert np.array_equal(_encode(sd, ids, lens, 128, max_tokens=512), got)   # micro-batch boundaries change no row
     monkeypatch.setenv("ANCE_CLS_TAIL", "0")
-    d_tail = float(np.abs(_encode(sd, ids, lens, 128) - want).max())
+    full_last_layer = _encode(sd, ids, lens, 128)
     monkeypatch.delenv("ANCE_CLS_TAIL")
+    d_tail = float(np.abs(full_last_layer - want).max())
     assert d_tail <= 2e-5, d_tail
+    # the CLS-only tail (K | V of every token, Q / attention-output / FFN of the [CLS] rows only, projected from compact rows) is the
+    # same arithmetic per element as the full last layer: not one bit may differ
+    assert np.array_equal(full_last_layer, got)
     sd3 = encoder_ref.random_state_dict(seed=6, n_layers=3, ln_jitter=0.1)
     lens5 = np.array([512, 511, 300, 129, 385, 512, 17, 256], dtype=np.int32)
     ids5 = synth.make_records(np.random.default_rng(9), len(lens5), 512, lens5.astype(np.int64))
