@@ -18,7 +18,9 @@ A "step" is one pass of the hot path over one batch of synthetic input, timed pe
 Both legs: W untimed warm-up steps, then exactly K steps between barrier + synchronize on both
 sides, MAX over ranks.  Rank 0 prints ONE JSON line.  `roofline` comes from HIP events the library
 records around every kernel launch on the launch stream during the timed steps; `cpu_baseline` is
-the oracle (a port of the reference CPU path) timed on this box's host cores on a bounded sample.
+the oracle (a port of the reference CPU path) timed on this box's host cores on a bounded sample;
+`power` (and `search.power`) are the board's socket power and shader clock sampled from the amdgpu
+hwmon files while the timed steps run -- reported only: both matrix-core encoder modes sit at the cap.
 """
 import argparse
 import json
@@ -311,6 +313,81 @@ def pmc_traffic(leg, kernel):
         return dict(ent, measured_in_this_run=False, source="profiles/pmc_traffic.json (scripts/gpu_pmc.sh, rocprofv3 --pmc passes)")
     except Exception:
         return None
+
+
+class PowerSampler:
+    """Socket power and shader clock of the device while a timed region runs (a thread reading the amdgpu hwmon files every 0.25 s;
+    `rocm-smi --json` when they are not readable): the split and fp16 encoder modes run AT the board's power cap, which is what
+    sets their clock.  Reported, never used; None when the platform offers neither source."""
+
+    def __init__(self, torch, dev_index):
+        import glob
+        self.files, self.samples, self.stop, self.thread, self.index = None, [], False, None, dev_index
+        try:
+            p = torch.cuda.get_device_properties(dev_index)
+            bdf = "%04x:%02x:%02x.0" % (getattr(p, "pci_domain_id", 0), p.pci_bus_id, p.pci_device_id)
+            dirs = glob.glob("/sys/bus/pci/devices/%s/hwmon/hwmon*" % bdf)
+        except Exception:
+            dirs = []
+        dirs = dirs or sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*"))
+        for d in dirs:
+            pw = [f for f in (d + "/power1_average", d + "/power1_input") if os.path.exists(f)]
+            if pw:
+                self.files = dict(power=pw[0], sclk=d + "/freq1_input", cap=d + "/power1_cap")
+                break
+
+    @staticmethod
+    def _read(path):
+        try:
+            with open(path) as f:
+                return float(f.read().strip())
+        except Exception:
+            return None
+
+    def _smi(self):
+        import subprocess
+        try:
+            out = json.loads(subprocess.run(["rocm-smi", "-d", str(self.index), "--showpower", "--showclocks", "--json"],
+                                            capture_output=True, text=True, timeout=5).stdout)
+            card = next(iter(out.values()))
+            pw = next((float(v) for k, v in card.items() if "Power" in k and "W" in k), None)
+            sc = next((float(v.strip("()Mhz")) for k, v in card.items() if k.startswith("sclk clock speed")), None)
+            return pw, sc
+        except Exception:
+            return None, None
+
+    def _loop(self):
+        while not self.stop:
+            if self.files:
+                pw, sc = self._read(self.files["power"]), self._read(self.files["sclk"])
+                pw, sc = (pw / 1e6 if pw is not None else None), (sc / 1e6 if sc is not None else None)
+            else:
+                pw, sc = self._smi()
+            if pw is not None:
+                self.samples.append((pw, sc))
+            time.sleep(0.25)
+
+    def __enter__(self):
+        import threading
+        self.thread = threading.Thread(target=self._loop, daemon=True)
+        self.thread.start()
+        return self
+
+    def __exit__(self, *exc):
+        self.stop = True
+        self.thread.join(timeout=10)
+
+    def report(self):
+        if not self.samples:
+            return None
+        pw = [x[0] for x in self.samples]
+        sc = [x[1] for x in self.samples if x[1] is not None]
+        cap = self._read(self.files["cap"]) if self.files else None
+        return {"socket_power_w": {"min": min(pw), "mean": sum(pw) / len(pw), "max": max(pw)},
+                "sclk_mhz": {"min": min(sc), "mean": sum(sc) / len(sc), "max": max(sc)} if sc else None,
+                "power_cap_w": cap / 1e6 if cap else None, "samples": len(pw),
+                "source": "amdgpu hwmon (sysfs), 0.25 s period, over the timed steps" if self.files else "rocm-smi --json over the timed steps",
+                "measured_in_this_run": True}
 
 
 def timed_steps(fn, steps, warmup, dist_on, torch):
@@ -704,7 +781,9 @@ def main():
                 for _ in range(max(a.warmup, 1) if mode == HEADLINE_MODE else 1):
                     step()
                 torch.cuda.synchronize()
-                dt = timed_steps(step, steps, 0, dist_on, torch)
+                with PowerSampler(torch, dev.index or 0) as ps:
+                    dt = timed_steps(step, steps, 0, dist_on, torch)
+                power = ps.report()
                 os.environ["ANCE_ENCODER_STREAMS"] = "1"
                 try:
                     enc1 = Encoder(sd, ARCH_ROBERTA, "roberta.", True, max_seq_len=min(a.seq_len, 512), max_tokens=a.max_tokens,
@@ -752,7 +831,7 @@ def main():
                 leg = {"value": pps, "unit": "passages/s", "ms_per_step": 1e3 * dt / steps, "steps": steps, "block": a.encode_block,
                        "encoder_precision": mode, "dtype": DTYPE_OF[mode], "arithmetic": ARITHMETIC_OF[mode],
                        "tokens_per_sec": pps * float(lens.mean()), "algorithmic_tflops": world * flops_alg * steps / dt / 1e12,
-                       "roofline": roof}
+                       "roofline": roof, "power": power}
                 e = None
                 if want_emb:  # the mode's embeddings of the block, for the distance between the modes
                     step()
@@ -769,6 +848,7 @@ def main():
             out["dtype"] = head["dtype"]
             out["encoder_precision"] = HEADLINE_MODE
             out["roofline"] = head["roofline"]
+            out["power"] = head["power"]  # the board while the timed steps ran (PowerSampler): both matrix-core modes sit at the cap
             out["encode"] = {"passages_per_sec": pps, "tokens_per_sec": head["tokens_per_sec"], "mean_len": float(lens.mean()),
                              "arithmetic": head["arithmetic"], "algorithmic_tflops": head["algorithmic_tflops"],
                              "padded_equiv_tflops": world * flops_pad * a.steps / (head["ms_per_step"] * 1e-3 * a.steps) / 1e12,
@@ -827,7 +907,8 @@ def main():
             _lib.profile_enable(True)
             if dist_on:
                 dist.comm = {}  # every device collective of the timed steps bracketed by events on its stream (Dist._timed)
-            dt = timed_steps(step_search, a.steps, 0, dist_on, torch)
+            with PowerSampler(torch, dev.index or 0) as ps_search:
+                dt = timed_steps(step_search, a.steps, 0, dist_on, torch)
             prof = _lib.profile_read()
             _lib.profile_enable(False)
             comm = dist.comm_ms() if dist_on else {}
@@ -869,7 +950,7 @@ def main():
                                                   for k_, v_ in comm.items()} if dist_on else None,
                              "comm_note": "rank 0's collectives of one step (all-to-all of the per-shard lists by query owner, gather of the merged "
                                           "blocks), issued on the exchange stream beside the next chunk's scan" if dist_on else None,
-                             "search_image_build_ms": build_ms,
+                             "search_image_build_ms": build_ms, "power": ps_search.report(),
                              "roofline": {"bound": bound,
                                           "kernel": "ip_topk_fast_kernel (fp16 MFMA 32x32x16 filter; algorithmic FLOPs = 2 nq n d = "
                                                     "1,536 per query-row pair)",
