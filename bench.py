@@ -828,6 +828,11 @@ def main():
                                       for c, v in prof.items() if v["count"]}}
                 if peak != PEAK_F32_TF:
                     roof["algorithmic_vs_fp32_mfma_peak"] = alg / PEAK_F32_TF
+                    # what the board sustains at its power cap (tools/power_probe.cpp): `peak` assumes 2.4 GHz, random operands allow ~1.7
+                    roof["sustained_mfma_rate_at_the_power_cap"] = {
+                        "bare_mfma_random_operands_tflops": 1678.0, "with_the_main_loops_fragment_reads_tflops": 1525.0,
+                        "executed_frac_of_the_latter": alg * mfma_per_product / 1525.0, "measured_in_this_run": False,
+                        "source": "profiles/r06_power_probe.txt (tools/power_probe.cpp, scripts/gpu_r6_power_probe.sh)"}
                 leg = {"value": pps, "unit": "passages/s", "ms_per_step": 1e3 * dt / steps, "steps": steps, "block": a.encode_block,
                        "encoder_precision": mode, "dtype": DTYPE_OF[mode], "arithmetic": ARITHMETIC_OF[mode],
                        "tokens_per_sec": pps * float(lens.mean()), "algorithmic_tflops": world * flops_alg * steps / dt / 1e12,
