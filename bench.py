@@ -320,15 +320,17 @@ class PowerSampler:
     `rocm-smi --json` when they are not readable): the split and fp16 encoder modes run AT the board's power cap, which is what
     sets their clock.  Reported, never used; None when the platform offers neither source."""
 
-    def __init__(self, torch, dev_index):
+    def __init__(self, torch, dev_index, hwmon_dirs=None):
         import glob
         self.files, self.samples, self.stop, self.thread, self.index = None, [], False, None, dev_index
-        try:
-            p = torch.cuda.get_device_properties(dev_index)
-            bdf = "%04x:%02x:%02x.0" % (getattr(p, "pci_domain_id", 0), p.pci_bus_id, p.pci_device_id)
-            dirs = glob.glob("/sys/bus/pci/devices/%s/hwmon/hwmon*" % bdf)
-        except Exception:
-            dirs = []
+        dirs = list(hwmon_dirs or [])
+        if not dirs:
+            try:  # the hwmon directory of THIS device (a box lists every card of the node under /sys/class/drm)
+                p = torch.cuda.get_device_properties(dev_index)
+                bdf = "%04x:%02x:%02x.0" % (getattr(p, "pci_domain_id", 0), p.pci_bus_id, p.pci_device_id)
+                dirs = glob.glob("/sys/bus/pci/devices/%s/hwmon/hwmon*" % bdf)
+            except Exception:
+                dirs = []
         dirs = dirs or sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*"))
         for d in dirs:
             pw = [f for f in (d + "/power1_average", d + "/power1_input") if os.path.exists(f)]

@@ -81,3 +81,25 @@ def test_roofline_evidence_helpers_quote_only_this_round(tmp_path, monkeypatch):
     assert bench.trace_avg_ns(name, bench.KERNEL_OF["gemm_ffn1"]) == 300000.0
     assert bench.trace_avg_ns(name, bench.KERNEL_OF["gemm_attn_out"]) == 200000.0
     assert bench.trace_avg_ns("missing.csv", "x") is None
+
+
+def test_power_sampler_reads_hwmon_files(tmp_path):
+    """bench.PowerSampler: socket power (uW) and shader clock (Hz) from an amdgpu hwmon directory, sampled by a thread while a timed
+    region runs; a platform without the files (and without rocm-smi devices) reports None instead of failing the bench."""
+    import time
+    import bench
+    d = tmp_path / "hwmon7"
+    d.mkdir()
+    (d / "power1_input").write_text("1396000000\n")
+    (d / "freq1_input").write_text("1572000000\n")
+    (d / "power1_cap").write_text("1400000000\n")
+    with bench.PowerSampler(None, 0, hwmon_dirs=[str(d)]) as ps:
+        time.sleep(0.7)
+    r = ps.report()
+    assert r["samples"] >= 2 and r["power_cap_w"] == 1400.0
+    assert r["socket_power_w"] == {"min": 1396.0, "mean": 1396.0, "max": 1396.0}
+    assert r["sclk_mhz"]["mean"] == 1572.0 and r["measured_in_this_run"] is True
+    empty = tmp_path / "hwmon8"
+    empty.mkdir()
+    ps2 = bench.PowerSampler(None, 0, hwmon_dirs=[str(empty)])
+    assert ps2.files is None or ps2.report() is None
