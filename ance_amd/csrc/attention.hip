@@ -272,7 +272,7 @@ __global__ void __launch_bounds__(64 * NW, 3) attention_kernel(const AttnArgs A)
 // unscaled lo halves, see common.h) and every product is three MFMAs:
 //     S^T = 2^-11 (K_hi Q_lo'^T + K_lo' Q_hi^T) + K_hi Q_hi^T          (Q carries log2(e) / 8: the softmax runs on exp2)
 //     O^T = 2^-11 (V_hi P_lo'^T + V_lo' P_hi^T) + V_hi P_hi^T          (two accumulator sets, combined once at the end)
-// LDS: 4 x keys x 64 halves + pads = 66 KB at 128 keys, 132 KB at 256; longer sequences stage their keys 256 at a time (the
+// LDS: 4 x keys x 64 halves = 64 KB at 128 keys, 128 KB at 256; longer sequences stage their keys 256 at a time (the
 // online softmax iterates key blocks anyway) and re-stage them for every pass of 128 queries.  Replaces the vector-unit kernel of
 // precise32.h (launch_attention32, kept behind ANCE_SPLIT_ATTN=0) at 8 x the speed for the lengths of config 2.
 // V in LDS (round 6, TR): ROW-major like K -- [key][64 dims + 8 pad] halves, staged by 16-byte writes -- and read as V^T fragments
@@ -559,7 +559,7 @@ int launch_attention_split(const float *qkv, _Float16 *ctx_pair, const int4 *des
                            int cls_only, hipStream_t st) {
     if (n_seq <= 0) return ANCE_OK;
     const int Tk = (max_seq_len + 31) & ~31;
-    const int kchunk = Tk <= 256 ? Tk : 256;  // keys staged at a time: 66 KB at 128 (two workgroups per CU), 132 KB at 256
+    const int kchunk = Tk <= 256 ? Tk : 256;  // keys staged at a time: 64 KB at 128 (two workgroups per CU), 128 KB at 256
     const size_t lds = attention_split_lds_bytes(kchunk);
     int dev = 0;
     (void)hipGetDevice(&dev);
