@@ -352,20 +352,11 @@ __global__ void __launch_bounds__(64 * NW, 2) attention_split_kernel(const float
                 } else
 #endif
                 if (e < kc * 8 && key < T) {
-#if defined(ATTN_DIAG_HEAD_MAJOR)  // measurement build: the BYTES of a head-major Q | K | V image ([part][head][token][64], 131,072 tokens): wrong values, same traffic
-                    const float *kp = qkv + ((size_t)(n_heads + h) * 131072 + (size_t)(tok0 + key)) * HD + ch * 8;
-                    const float *vp_ = qkv + ((size_t)(2 * n_heads + h) * 131072 + (size_t)(tok0 + key)) * HD + ch * 8;
-                    kv[it][0] = *reinterpret_cast<const f32x4 *>(kp);
-                    kv[it][1] = *reinterpret_cast<const f32x4 *>(kp + 4);
-                    kv[it][2] = *reinterpret_cast<const f32x4 *>(vp_);
-                    kv[it][3] = *reinterpret_cast<const f32x4 *>(vp_ + 4);
-#else
                     const float *kp = qkv + (size_t)(tok0 + key) * ld + n_heads * HD + h * HD + ch * 8;
                     kv[it][0] = *reinterpret_cast<const f32x4 *>(kp);
                     kv[it][1] = *reinterpret_cast<const f32x4 *>(kp + 4);
                     kv[it][2] = *reinterpret_cast<const f32x4 *>(kp + n_heads * HD);
                     kv[it][3] = *reinterpret_cast<const f32x4 *>(kp + n_heads * HD + 4);
-#endif
                 }
             }
 #pragma unroll
@@ -406,11 +397,7 @@ __global__ void __launch_bounds__(64 * NW, 2) attention_split_kernel(const float
         f16x8 qh[4], ql[4];
         {
             // (cls_only: the one query of sequence s is row s of the Q columns -- encoder.hip projects the [CLS] rows compactly)
-#if defined(ATTN_DIAG_HEAD_MAJOR)
-            const float *qp = qkv + ((size_t)h * 131072 + (cls_only ? (size_t)s : (size_t)(tok0 + min(qb0 + i, T - 1)))) * HD + 32 * g;
-#else
             const float *qp = qkv + (cls_only ? (size_t)s : (size_t)(tok0 + min(qb0 + i, T - 1))) * ld + h * HD + 32 * g;
-#endif
             f32x4 xq[8];
 #pragma unroll
             for (int sx = 0; sx < 8; ++sx) xq[sx] = *reinterpret_cast<const f32x4 *>(qp + sx * 4);
