@@ -70,6 +70,8 @@ def parse():
     p.add_argument("--full-queries", type=int, default=N_TRAIN_QUERIES)
     p.add_argument("--full-dev-queries", type=int, default=6980)
     p.add_argument("--negative-sample", type=int, default=20)
+    p.add_argument("--skip-mfma-probe", action="store_true",
+                   help="do not run tools/power_probe (the sustained MFMA rate of this board at its power cap, ~12 s)")
     p.add_argument("--skip-other-configs", action="store_true",
                    help="skip the encode legs of BASELINE configs[2..4] (L=512, MaxP 4x512, DPR BERT L=256)")
     p.add_argument("--other-config-steps", type=int, default=3, help="timed steps of each other-config leg (at most 6)")
@@ -390,6 +392,25 @@ class PowerSampler:
                 "power_cap_w": cap / 1e6 if cap else None, "samples": len(pw),
                 "source": "amdgpu hwmon (sysfs), 0.25 s period, over the timed steps" if self.files else "rocm-smi --json over the timed steps",
                 "measured_in_this_run": True}
+
+
+def sustained_mfma_rate(seconds=2.0):
+    """tools/power_probe (built by __graft_entry__.build): the fp16 MFMA rate THIS board sustains -- 8 waves per CU, the split GEMM's
+    24 MFMAs per step -- bare, on zero operands, with the main loop's LDS fragment reads, with LDS-DMA traffic on top; each with the
+    socket power and shader clock it ran at.  None when the tool is not there."""
+    import re
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "power_probe")
+    if not os.path.exists(exe):
+        return None
+    try:
+        out = subprocess.run([exe, str(seconds)], capture_output=True, text=True, timeout=120).stdout
+    except Exception:
+        return None
+    res = {}
+    for m in re.finditer(r"^(\S+)\s+([0-9.]+) TF executed.*?power\s+([0-9.-]+) W\s+sclk\s+([0-9.-]+) MHz", out, flags=re.M):
+        res[m.group(1)] = {"tflops": float(m.group(2)), "socket_power_w": float(m.group(3)), "sclk_mhz": float(m.group(4))}
+    return res or None
 
 
 def timed_steps(fn, steps, warmup, dist_on, torch):
@@ -767,6 +788,8 @@ def main():
             flops_pad = a.encode_block * (169869312.0 * a.seq_len + 36864.0 * a.seq_len ** 2 + 1179648.0)
 
             want_emb = not a.skip_precise and world == 1
+            # the rate the matrix pipe sustains on THIS board (tools/power_probe: ~12 s), single-GPU runs only, before anything is timed
+            probe_live = [sustained_mfma_rate() if (world == 1 and not a.skip_mfma_probe) else None]
 
             def measure_mode(mode, steps, kernels, peak, mfma_per_product, trace_label):
                 """K timed steps of `mode` on the product handle (two internal streams), then the same records on a single-stream
@@ -831,10 +854,15 @@ def main():
                 if peak != PEAK_F32_TF:
                     roof["algorithmic_vs_fp32_mfma_peak"] = alg / PEAK_F32_TF
                     # what the board sustains at its power cap (tools/power_probe.cpp): `peak` assumes 2.4 GHz, random operands allow ~1.7
+                    live = probe_live[0]
+                    bare = live["mfma"]["tflops"] if live else 1678.0
+                    with_reads = live["mfma+lds"]["tflops"] if live else 1525.0
                     roof["sustained_mfma_rate_at_the_power_cap"] = {
-                        "bare_mfma_random_operands_tflops": 1678.0, "with_the_main_loops_fragment_reads_tflops": 1525.0,
-                        "executed_frac_of_the_latter": alg * mfma_per_product / 1525.0, "measured_in_this_run": False,
-                        "source": "profiles/r06_power_probe.txt (tools/power_probe.cpp, scripts/gpu_r6_power_probe.sh)"}
+                        "bare_mfma_random_operands_tflops": bare, "with_the_main_loops_fragment_reads_tflops": with_reads,
+                        "executed_frac_of_the_latter": alg * mfma_per_product / with_reads, "measured_in_this_run": bool(live),
+                        "cases": live,
+                        "source": "tools/power_probe run by this bench on this box (2 s per case, before the timed legs)" if live else
+                                  "profiles/r06_power_probe.txt (tools/power_probe.cpp, scripts/gpu_r6_power_probe.sh)"}
                 leg = {"value": pps, "unit": "passages/s", "ms_per_step": 1e3 * dt / steps, "steps": steps, "block": a.encode_block,
                        "encoder_precision": mode, "dtype": DTYPE_OF[mode], "arithmetic": ARITHMETIC_OF[mode],
                        "tokens_per_sec": pps * float(lens.mean()), "algorithmic_tflops": world * flops_alg * steps / dt / 1e12,
